@@ -1,0 +1,210 @@
+"""Deterministic synthetic weights / clips / targets shared by the golden generator and the tests.
+
+Everything is drawn from numpy PCG64 streams keyed by crc32(name), so the same tensors can be
+rebuilt on any machine without shipping 90 M parameters.  The key/shape list is our own
+statement of the reference's state_dict layout (SURVEY.md section 5 "checkpoint"); the golden
+generator asserts it against the real reference and freezes it in tests/golden/state_keys.json.
+"""
+import math
+import re
+import zlib
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from oracle import phnet_cpu as O
+
+
+def _rng(name: str, salt: int = 0):
+    return np.random.default_rng([zlib.crc32(name.encode()), salt])
+
+
+def state_spec(g: O.Geometry) -> "OrderedDict[str, tuple]":
+    """name -> shape, in the reference's registration order."""
+    spec = OrderedDict()
+    C, S, N, P = g.feat_channels, g.num_points, g.num_priors, g.sample_points
+
+    def bn(prefix, c):
+        spec[prefix + ".weight"] = (c,)
+        spec[prefix + ".bias"] = (c,)
+        spec[prefix + ".running_mean"] = (c,)
+        spec[prefix + ".running_var"] = (c,)
+        spec[prefix + ".num_batches_tracked"] = ()
+
+    def lin(prefix, i, o):
+        spec[prefix + ".weight"] = (o, i)
+        spec[prefix + ".bias"] = (o,)
+
+    def ln(prefix, *shape):
+        spec[prefix + ".weight"] = tuple(shape)
+        spec[prefix + ".bias"] = tuple(shape)
+
+    p = "backbone.backbone.model."
+    spec[p + "conv1.weight"] = (64, 3, 7, 7)
+    bn(p + "bn1", 64)
+    cin = 64
+    for li, nb in enumerate(O.BLOCKS_PER_LAYER[g.arch]):
+        w = O.LAYER_WIDTH[li]
+        for bi in range(nb):
+            q = f"{p}layer{li + 1}.{bi}."
+            spec[q + "conv1.weight"] = (w, cin, 3, 3)
+            bn(q + "bn1", w)
+            spec[q + "conv2.weight"] = (w, w, 3, 3)
+            bn(q + "bn2", w)
+            if bi == 0 and li > 0:
+                spec[q + "downsample.0.weight"] = (w, cin, 1, 1)
+                bn(q + "downsample.1", w)
+            cin = w
+    p = "backbone.neck."
+    for i, c in enumerate(O.LAYER_WIDTH[1:]):
+        spec[f"{p}lateral_convs.{i}.conv.weight"] = (C, c, 1, 1)
+        spec[f"{p}lateral_convs.{i}.conv.bias"] = (C,)
+    for i in range(3):
+        spec[f"{p}fpn_convs.{i}.conv.weight"] = (C, C, 3, 3)
+        spec[f"{p}fpn_convs.{i}.conv.bias"] = (C,)
+    d = "detNet."
+    spec[d + "sample_x_indexs"] = (P,)
+    spec[d + "prior_feat_ys"] = (P,)
+    spec[d + "prior_ys"] = (S,)
+    spec[d + "priors"] = (N, 6 + S)
+    spec[d + "priors_on_featmap"] = (N, P)
+    spec[d + "prior_embeddings.weight"] = (N, 3)
+    for suffix, width in (("", C), ("_sec", 2 * C)):
+        for kind in ("reg", "cls", "iou"):
+            for idx in (0, 2):
+                lin(f"{d}{kind}_modules{suffix}.{idx}", width, width)
+        lin(f"{d}reg_layers{suffix}", width, 4)
+        lin(f"{d}cls_layers{suffix}", width, 2)
+        lin(f"{d}iou_layers{suffix}", width, S)
+    E = 2 * C
+    for li in range(2):
+        q = f"{d}transformer_Dec.layers.{li}."
+        for att in ("self_attn", "multihead_attn"):
+            spec[q + att + ".in_proj_weight"] = (3 * E, E)
+            spec[q + att + ".in_proj_bias"] = (3 * E,)
+            lin(q + att + ".out_proj", E, E)
+        lin(q + "linear1", E, 256)
+        lin(q + "linear2", 256, E)
+        for k in (1, 2, 3):
+            ln(q + f"norm{k}", E)
+    ln(d + "transformer_Dec.norm", E)
+    spec[d + "PositionEmbedding.embed.weight"] = (N, C)
+    for s in range(g.refine_layers):
+        q = f"{d}DHead_series.{s}."
+        lin(q + "dynamic_layer_1.0", C, C * 2 * C // 8)
+        lin(q + "dynamic_layer_1.1", C * 2 * C // 8, C * 2 * C)
+        lin(q + "dynamic_layer_2.0", 2 * C * P, C * 2 * C // 8)
+        lin(q + "dynamic_layer_2.1", C * 2 * C // 8, C * 2 * C)
+        ln(q + "norm1", 2 * C)
+        ln(q + "norm2", C)
+        lin(q + "out_layer.0", C * P, 6 * C)
+        lin(q + "out_layer.1", 6 * C, C)
+        ln(q + "norm3", C)
+    spec[d + "pro_embedding.weight"] = (N, C)
+    r = d + "router."
+    for s in range(g.refine_layers):
+        lin(f"{r}layers.{s}.0", C * P, C * P // 4)
+        lin(f"{r}layers.{s}.2", C * P // 4, 1)
+    for s in range(g.refine_layers):
+        ln(f"{r}pre_norm.{s}", C, P)
+    for s in range(g.refine_layers):
+        for b in range(4):
+            q = f"{r}DWNets.{s}.{b}."
+            spec[q + "0.weight"] = (N, 1, 3, 3)
+            spec[q + "0.bias"] = (N,)
+            ln(q + "1", C, P)
+            spec[q + "3.weight"] = (N, 1, 3, 3)
+            spec[q + "3.bias"] = (N,)
+            ln(q + "4", C, P)
+    return spec
+
+
+_NORM_RE = re.compile(r"(\.bn\d|downsample\.1|\.norm\d?|pre_norm\.\d|DWNets\.\d\.\d\.[14])\.(weight|bias)$")
+
+
+def synth_tensor(name: str, shape: tuple, g: O.Geometry) -> torch.Tensor:
+    r = _rng(name)
+    f32 = np.float32
+    if name.endswith("num_batches_tracked"):
+        return torch.zeros((), dtype=torch.long)
+    if name.endswith("running_mean"):
+        return torch.from_numpy(r.normal(0, 0.1, shape).astype(f32))
+    if name.endswith("running_var"):
+        return torch.from_numpy(r.uniform(0.5, 1.5, shape).astype(f32))
+    m = _NORM_RE.search(name)
+    if m:
+        a = r.uniform(0.5, 1.5, shape) if m.group(2) == "weight" else r.normal(0, 0.1, shape)
+        return torch.from_numpy(a.astype(f32))
+    if name.endswith("prior_embeddings.weight"):
+        e = O.initial_anchor_embeddings(g).numpy()
+        return torch.from_numpy((e + r.normal(0, 0.004, e.shape)).astype(f32))
+    if name.endswith("pro_embedding.weight"):
+        return torch.from_numpy(r.normal(0, 1.0, shape).astype(f32))
+    if name.endswith("PositionEmbedding.embed.weight"):
+        return torch.from_numpy(r.uniform(0, 1.0, shape).astype(f32))
+    if name.endswith(".bias") or name.endswith("in_proj_bias"):
+        b = r.normal(0, 0.05, shape).astype(f32)
+        if re.search(r"reg_layers(_sec)?\.bias$", name):
+            b = (b * 0.2).astype(f32)
+            b[3] += 0.6                     # lane length ~0.6 of the image so that NMS has work to do
+        return torch.from_numpy(b)
+    if len(shape) == 4:                     # conv weights
+        fan_in = shape[1] * shape[2] * shape[3]
+        gain = 1.0 if shape[1] == 1 else math.sqrt(2.0)
+        return torch.from_numpy(r.normal(0, gain / math.sqrt(fan_in), shape).astype(f32))
+    if len(shape) == 2:                     # linear weights
+        std = 1.0 / math.sqrt(shape[1])
+        if re.search(r"reg_layers(_sec)?\.weight$", name):
+            std *= 0.1
+        if re.search(r"iou_layers(_sec)?\.weight$", name):
+            std *= 0.02
+        return torch.from_numpy(r.normal(0, std, shape).astype(f32))
+    raise KeyError(name)
+
+
+def make_state(g: O.Geometry) -> "OrderedDict[str, torch.Tensor]":
+    sd = OrderedDict()
+    for name, shape in state_spec(g).items():
+        if name.split(".")[-1] in ("sample_x_indexs", "prior_feat_ys", "prior_ys", "priors", "priors_on_featmap"):
+            continue
+        sd[name] = synth_tensor(name, shape, g)
+    pri, on_map = O.priors_from_embeddings(sd["detNet.prior_embeddings.weight"], g)
+    sd["detNet.sample_x_indexs"] = O.sample_x_indexs(g)
+    sd["detNet.prior_feat_ys"] = O.prior_feat_ys(g)
+    sd["detNet.prior_ys"] = O.prior_ys(g)
+    sd["detNet.priors"] = pri.clone()
+    sd["detNet.priors_on_featmap"] = on_map.clone()
+    return OrderedDict((k, sd[k]) for k in state_spec(g))
+
+
+def make_clip(g: O.Geometry, T: int, seed: int = 3407) -> torch.Tensor:
+    r = np.random.default_rng([seed, T, g.img_h, g.img_w])
+    return torch.from_numpy(r.standard_normal((T, 3, g.img_h, g.img_w), dtype=np.float32))
+
+
+def make_targets(g: O.Geometry, T: int, n_lanes: int = 3, max_lanes_in_label: int = 4) -> torch.Tensor:
+    """Straight synthetic lanes in the label layout of libs/dataset/openlane/transforms.py:264-297:
+    [neg flag, pos flag, start_y, start_x/(W-1), theta, len/n_strips, xs in pixels (bottom->top), -1e5 invalid]."""
+    S, W, H = g.num_points, g.img_w, g.img_h
+    strip = H / g.n_strips
+    out = np.full((T, max_lanes_in_label, 6 + S), -1e5, dtype=np.float32)
+    out[:, :, 0] = 1
+    out[:, :, 1] = 0
+    x0s, slopes = (0.2, 0.45, 0.7, 0.85), (4.0, 0.5, -4.0, -6.0)
+    for t in range(T):
+        for j in range(min(n_lanes, max_lanes_in_label)):
+            xs = x0s[j] * W + 5.0 * t + slopes[j] * np.arange(S)
+            valid = (xs >= 0) & (xs < W)
+            n = int(np.argmin(valid)) if not valid.all() else S
+            n = min(n, S - 4 - j)
+            xs = xs[:n]
+            th = [math.atan(i * strip / (xs[i] - xs[0] + 1e-5)) / math.pi for i in range(1, n)]
+            th = [v if v > 0 else 1 - abs(v) for v in th]
+            out[t, j, 0], out[t, j, 1] = 0, 1
+            out[t, j, 2] = 0.0
+            out[t, j, 3] = xs[0] / (W - 1)
+            out[t, j, 4] = sum(th) / len(th)
+            out[t, j, 5] = n / g.n_strips
+            out[t, j, 6:6 + n] = xs
+    return torch.from_numpy(out)

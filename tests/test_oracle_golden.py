@@ -1,0 +1,117 @@
+"""Pins the CPU oracle (oracle/phnet_cpu.py) to fixtures produced by the reference's own Python
+(tests/golden/make_goldens.py).  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import lane_nms as ONMS
+from oracle import phnet_cpu as O
+from tests import synth
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _load(name):
+    return dict(np.load(os.path.join(GOLD, name)))
+
+
+def _train(g, T):
+    sd = synth.make_state(g)
+    for k, v in sd.items():
+        if v.is_floating_point() and "running" not in k and k.split(".")[-1] not in (
+                "prior_feat_ys", "prior_ys", "priors", "priors_on_featmap"):
+            v.requires_grad_(True)
+    col = {}
+    loss = O.clip_forward(sd, synth.make_clip(g, T), synth.make_targets(g, T), g, training=True,
+                          track_running_stats=True, collect=col)
+    loss.backward()
+    return sd, loss, col
+
+
+def _check_train(gold, sd, loss, col, g, names, full):
+    assert abs(loss.item() - gold["train_loss"]) <= 2e-4 * abs(gold["train_loss"])
+    T = len(col["frames"])
+    for t in range(T):
+        fo = col["frames"][t]
+        gate = torch.stack([x[0, :, 0] for x in fo.gates]).detach().numpy()
+        np.testing.assert_allclose(gate, gold["train_gate"][t], atol=2e-5)
+        for s in range(3):
+            m = col["positives"][t][s].numpy()
+            assert m.tolist() == [i for i in gold["train_matched"][t, s].tolist() if i >= 0]
+        if "train_fir" in gold:
+            fir = torch.stack([x[0] for x in fo.predictions_fir]).detach().numpy()
+            sec = torch.stack([x[0] for x in fo.predictions_sec]).detach().numpy()
+            np.testing.assert_allclose(fir, gold["train_fir"][t], atol=1e-4, rtol=1e-4)
+            np.testing.assert_allclose(sec, gold["train_sec"][t], atol=1e-4, rtol=1e-4)
+    if full:
+        for j in range(3):
+            np.testing.assert_allclose(col["fpn"][j].detach().numpy(), gold[f"train_fpn{j}"], atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(sd["backbone.backbone.model.bn1.running_mean"].numpy(), gold["train_bn1_running_mean"], atol=1e-6)
+    np.testing.assert_allclose(sd["backbone.backbone.model.bn1.running_var"].numpy(), gold["train_bn1_running_var"], rtol=1e-5)
+    for i, k in enumerate(names):
+        gr = sd[k].grad
+        assert gr is not None, k
+        ref = gold["train_grad_norm"][i]
+        assert abs(float(gr.double().norm()) - ref) <= 2e-3 * ref + 1e-6, (k, float(gr.double().norm()), ref)
+        head = gr.flatten()[:4].double().numpy()
+        np.testing.assert_allclose(head, gold["train_grad_head"][i][:len(head)], rtol=5e-3, atol=2e-3 * ref / max(1.0, gr.numel() ** 0.5) + 1e-7)
+
+
+def _check_eval(gold, g, T):
+    sd = synth.make_state(g)
+    with torch.no_grad():
+        dec = O.clip_forward(sd, synth.make_clip(g, T, seed=77), None, g, training=False, nms_fn=ONMS.lane_nms)
+    for t, d in enumerate(dec):
+        np.testing.assert_allclose(d["lines"].numpy(), gold["eval_lines"][t], atol=1e-4, rtol=1e-4)
+        assert (d["keep_inds"].numpy() == gold["eval_keep_inds"][t]).all()
+        assert d["keep"].tolist() == [i for i in gold["eval_keep"][t].tolist() if i >= 0]
+        assert len(d["lanes"]) == int((gold["eval_lane_npts"][t] > 0).sum())
+        for j, (pts, sx, sy, conf) in enumerate(d["lanes"]):
+            n = int(gold["eval_lane_npts"][t, j])
+            assert pts.shape == (n, 2)
+            np.testing.assert_allclose(pts, gold["eval_lane_pts"][t, j, :n], atol=1e-5)
+            np.testing.assert_allclose([sx, sy, conf], gold["eval_lane_meta"][t, j], atol=1e-4)
+
+
+def test_state_spec_matches_reference_state_dict():
+    keys = json.load(open(os.path.join(GOLD, "state_keys.json")))
+    for arch in ("resnet18", "resnet34"):
+        spec = synth.state_spec(O.Geometry(arch=arch))
+        assert list(spec) == list(keys[arch])
+        assert all(list(spec[k]) == keys[arch][k] for k in spec)
+
+
+def test_tiny_train_matches_reference():
+    g = O.Geometry(img_h=64, img_w=160, arch="resnet18")
+    gold = _load("tiny_r18_64x160.npz")
+    names = json.load(open(os.path.join(GOLD, "grad_names_resnet18.json")))
+    sd, loss, col = _train(g, 3)
+    _check_train(gold, sd, loss, col, g, names, full=True)
+
+
+def test_tiny_eval_matches_reference():
+    _check_eval(_load("tiny_r18_64x160.npz"), O.Geometry(img_h=64, img_w=160, arch="resnet18"), 4)
+
+
+def test_config1_single_frame_r18():
+    g = O.Geometry(arch="resnet18")
+    gold = _load("config1_r18_320x800.npz")
+    sd = synth.make_state(g)
+    with torch.no_grad():
+        feats = O.fpn_neck(sd, O.resnet_trunk(sd, synth.make_clip(g, 1), g, training=False))
+    for j, f in enumerate(feats):
+        np.testing.assert_allclose(f[..., ::4, ::5].numpy(), gold[f"fpn{j}_strided"], atol=5e-5, rtol=1e-5)
+        np.testing.assert_allclose(f.double().sum(dim=(2, 3)).numpy(), gold[f"fpn{j}_chansum"], rtol=1e-4, atol=1e-2)
+    _check_eval(gold, g, 1)
+
+
+def test_config2_clip_r34_train_and_eval():
+    g = O.Geometry(arch="resnet34")
+    gold = _load("config2_r34_320x800.npz")
+    names = json.load(open(os.path.join(GOLD, "grad_names_resnet34.json")))
+    sd, loss, col = _train(g, 5)
+    _check_train(gold, sd, loss, col, g, names, full=False)
+    _check_eval(gold, g, 5)
