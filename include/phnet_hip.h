@@ -1,0 +1,100 @@
+/* C-ABI of libphnet_hip.so: the MI355X (gfx950) kernels behind PHNet's per-clip hot path.
+ *
+ * This is the drop-in boundary (DESIGN.md "Boundary"): plain pointers and sizes, no torch types.
+ * The only native FFI the reference has on this path is the pybind11 module nms_impl
+ * (libs/ops/csrc/nms.cpp:44-61 -> nms_kernel.cu:147-192); phnet_lane_nms replaces it.  Every other entry
+ * point replaces an ATen/cuDNN/cuBLAS call the reference's Python makes (file:line given per function) and
+ * follows the same conventions:
+ *   - all pointers are DEVICE pointers (hipMalloc / torch.cuda memory), fp32 unless stated otherwise;
+ *   - outputs and workspaces are CALLER-allocated; nothing here allocates, frees or synchronises;
+ *   - `stream` is a hipStream_t (NULL = the legacy default stream); kernels are enqueued, not awaited;
+ *   - return value: 0 = enqueued, <0 = error (no work enqueued unless stated):
+ *       PHNET_ERR_ARG (-1) bad shape / null pointer / unsupported size,
+ *       PHNET_ERR_WORKSPACE (-2) workspace too small, PHNET_ERR_LAUNCH (-3) HIP launch error;
+ *   - re-entrant and thread-safe (no global state).
+ * Activation layout is NHWC; convolution weights are OHWI ([Co][R][S][Ci]) = the memory order of a
+ * torch.channels_last OIHW parameter, so reference checkpoints load without a re-layout pass.
+ */
+#ifndef PHNET_HIP_H
+#define PHNET_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PHNET_OK 0
+#define PHNET_ERR_ARG (-1)
+#define PHNET_ERR_WORKSPACE (-2)
+#define PHNET_ERR_LAUNCH (-3)
+#define PHNET_ABI_VERSION 1
+
+int phnet_abi_version(void);
+
+/* ---- lane NMS: replaces nms_impl.nms_forward (libs/ops/csrc/nms.cpp:44-57, nms_kernel.cu:26-192) ----
+ * rows   [frames][k_max][5+n_offsets]  (cls0, cls1, start_y, start_x_px, length_strips, x_0.. px)
+ * scores [frames][k_max];  counts [frames] int32 valid rows per frame, or NULL (= k_max for every frame)
+ * keep [frames][k_max] int64 (first num entries valid, rest 0), num_to_keep [frames] int64,
+ * parent [frames][k_max] int64 (1-based group id, 0 = none).  Score ties are broken by lower row index.
+ * Limits: k_max <= ~900 (single-workgroup design), n_offsets <= 250. */
+int phnet_lane_nms(const float* rows, const float* scores, const int32_t* counts, int64_t frames,
+                   int64_t k_max, int32_t n_offsets, float thresh, int64_t top_k,
+                   int64_t* keep, int64_t* num_to_keep, int64_t* parent, void* stream);
+
+/* ---- lane-anchor ROI pooling: replaces F.grid_sample(..., align_corners=True) + permutes
+ * (libs/models/Router4OL.py:132-150, 269-272) and its backward (ATen grid_sampler_2d_backward).
+ * fmap [B][h][w][64]; xs [B][N][P] = priors_on_featmap (un-flipped); ys [P] = prior_feat_ys; out [B][N][P][64]. */
+int phnet_roi_pool_fwd(const float* fmap, const float* xs, const float* ys, float* out,
+                       int32_t B, int32_t N, int32_t P, int32_t h, int32_t w, int32_t C, void* stream);
+/* dmap [B][h][w][64] is accumulated into (may be NULL); dxs [B][N][P] is overwritten (may be NULL). */
+int phnet_roi_pool_bwd(const float* dout, const float* fmap, const float* xs, const float* ys,
+                       float* dmap, float* dxs,
+                       int32_t B, int32_t N, int32_t P, int32_t h, int32_t w, int32_t C, void* stream);
+
+/* ---- convolution / linear on fp32 MFMA: replaces F.conv2d (libs/models/resnet.py:79-95,293-307;
+ * libs/models/fpn.py:109-163) and F.linear (Router4OL.py:308-392, utils/dynamic_head.py:31-59, Router.py:72-81).
+ * x [N][Hi][Wi][Ci], w [Co][R][S][Ci], bias [Co] or NULL, y [N][Ho][Wo][Co]; Ci%4==0, Co%4==0.
+ * workspace optional (split-K partial sums; recommended: >= 16*N*Ho*Wo*Co*4 bytes for small grids). */
+int phnet_conv2d_fwd(const float* x, const float* w, const float* bias, float* y,
+                     int32_t N, int32_t Hi, int32_t Wi, int32_t Ci, int32_t Co, int32_t R, int32_t S,
+                     int32_t stride, int32_t pad, int32_t relu, void* workspace, uint64_t ws_bytes, void* stream);
+int phnet_conv2d_dgrad(const float* dy, const float* w, float* dx,
+                       int32_t N, int32_t Hi, int32_t Wi, int32_t Ci, int32_t Co, int32_t R, int32_t S,
+                       int32_t stride, int32_t pad, void* workspace, uint64_t ws_bytes, void* stream);
+uint64_t phnet_conv2d_wgrad_workspace(int32_t N, int32_t Hi, int32_t Wi, int32_t Ci, int32_t Co,
+                                      int32_t R, int32_t S, int32_t stride, int32_t pad);
+int phnet_conv2d_wgrad(const float* dy, const float* x, float* dw,
+                       int32_t N, int32_t Hi, int32_t Wi, int32_t Ci, int32_t Co, int32_t R, int32_t S,
+                       int32_t stride, int32_t pad, int32_t accumulate, void* workspace, uint64_t ws_bytes, void* stream);
+/* stem helpers: NCHW 3-channel frames -> NHWC padded to 4 channels; innermost-dimension pad/truncate. */
+int phnet_nchw3_to_nhwc4(const float* x, float* y, int32_t N, int32_t H, int32_t W, void* stream);
+int phnet_pad_channels(const float* src, float* dst, int64_t rows, int32_t cs, int32_t cd, void* stream);
+
+/* ---- BatchNorm2d / ReLU / residual: replaces F.batch_norm + relu + add (libs/models/resnet.py:79-95, 293-297) ---- */
+uint64_t phnet_channel_partials_size(int64_t M, int32_t C);   /* floats needed in `partial` */
+int phnet_bn_fwd_stats(const float* x, int64_t M, int32_t C, float eps, float momentum,
+                       const float* gamma, const float* beta, float* running_mean, float* running_var,
+                       float* save_mean, float* save_invstd, float* scale, float* shift,
+                       float* partial, int32_t training, void* stream);
+int phnet_bn_apply(const float* x, const float* scale, const float* shift, const float* residual, float* y,
+                   int64_t M, int32_t C, int32_t relu, void* stream);
+int phnet_bn_bwd(const float* dy, const float* x, const float* y, const float* save_mean,
+                 const float* save_invstd, const float* gamma, float* dx, float* dres,
+                 float* dgamma, float* dbeta, float* partial, float* c1, float* c2,
+                 int64_t M, int32_t C, int32_t relu, int32_t dres_accumulate, int32_t param_accumulate, void* stream);
+
+/* ---- MaxPool2d(3,2,1): libs/models/resnet.py:217,297 ---- */
+int phnet_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* argmax, int32_t N, int32_t Hi, int32_t Wi, int32_t C, void* stream);
+int phnet_maxpool3x3s2_bwd(const float* dy, const uint8_t* argmax, float* dx, int32_t N, int32_t Hi, int32_t Wi, int32_t C, void* stream);
+
+/* ---- FPN top-down add: laterals[i-1] += F.interpolate(laterals[i], size=..., mode='nearest') (libs/models/fpn.py:127-141) ---- */
+int phnet_upsample_add(float* fine, const float* coarse, int32_t N, int32_t H, int32_t W, int32_t h, int32_t w, int32_t C, void* stream);
+int phnet_upsample_add_bwd(const float* dfine, float* dcoarse, int32_t N, int32_t H, int32_t W, int32_t h, int32_t w, int32_t C, void* stream);
+
+/* ---- bias gradients: column sums of [M][C] ---- */
+uint64_t phnet_colsum_workspace(int64_t M, int32_t C);
+int phnet_colsum(const float* a, float* out, int64_t M, int32_t C, int32_t accumulate, void* workspace, uint64_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

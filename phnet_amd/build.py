@@ -1,0 +1,43 @@
+"""Builds phnet_amd/lib/libphnet_hip.so (gfx950) from phnet_amd/csrc/*.hip with hipcc.  In-tree, no JIT cache."""
+import glob
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "lib", "obj")
+SO = os.path.join(HERE, "lib", "libphnet_hip.so")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    hdrs = glob.glob(os.path.join(CSRC, "*.h"))
+    newest_hdr = max([os.path.getmtime(h) for h in hdrs] + [0.0])
+    objs, procs = [], []
+    for s in srcs:
+        o = os.path.join(OBJ, os.path.basename(s)[:-4] + ".o")
+        objs.append(o)
+        if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), newest_hdr):
+            if verbose:
+                print("[phnet_amd.build] hipcc", os.path.basename(s), flush=True)
+            procs.append((s, subprocess.Popen([_hipcc(), *FLAGS, "-c", s, "-o", o])))
+    for s, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError(f"hipcc failed on {s}")
+    if procs or not os.path.exists(SO):
+        subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO, *objs])
+    return SO
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,516 @@
+// Implicit-GEMM convolution / linear kernels on fp32 MFMA for gfx950 (NHWC activations, OHWI weights).
+//
+// Replaces, for the hot path of SURVEY.md 8(a): the cuDNN convolutions behind
+//   libs/models/resnet.py:79-95,293-307 (trunk), libs/models/fpn.py:109-163 (neck)
+// and the cuBLAS addmm behind every nn.Linear of the head (Router4OL.py:308-392,
+// utils/dynamic_head.py:31-59, Router.py:72-81), forward, data-gradient and weight-gradient.
+//
+//   forward : out[m][co] = sum_{r,q,c} X[n, oy*s-p+r, ox*s-p+q, c] * W[co][r][q][c]      (+bias)(+relu)
+//             GEMM  M = N*Ho*Wo pixels, N = Co, K = R*S*Ci;  A gathered on the fly (K-contiguous),
+//             B = W as stored (K-contiguous).
+//   dgrad   : dX[m][c] = sum_{r,q,co} dY[n, (y+p-r)/s, (x+p-q)/s, co] * W[co][r][q][c]
+//             same kernel: A gathered from dY with "input dilation" s, B read K-strided straight out
+//             of the OHWI weights (row (r,q,co) -> W[co][R-1-r'][S-1-q'][:]) - no weight transpose pass.
+//   wgrad   : dW[co][r][q][c] = sum_pixels dY[pix][co] * X[pix shifted by (r,q)][c]
+//             GEMM  M = Co, N = R*S*Ci, K = pixels (split over blockIdx.z, deterministic 2-pass reduce);
+//             both operands K-strided.
+// A Linear layer is the R=S=1 case on an [M,1,1,K] image.
+//
+// Roofline: MFMA-bound (f32-input MFMA, 157.3 TF/s dense).  Algorithmic FLOPs = 2*M*N*K.
+#include "igemm.h"
+
+using namespace igemm;
+
+namespace {
+
+struct ConvShape {
+    int N, Hi, Wi, Ci;       // A-side image (input for fwd, dY for dgrad)
+    int Ho, Wo, Co;          // GEMM output image
+    int R, S;
+    int stride, pad, in_dil; // coordinate: t = o*stride - pad + r ; valid iff t % in_dil == 0 ; i = t / in_dil
+    int splits;              // split-K factor (blockIdx.z)
+    int k_per_split;         // multiple of BK
+};
+
+struct RowCoord { int base, iy0, ix0; bool ok; };
+
+template <int BM, int BN, bool B_DGRAD>
+__global__ __launch_bounds__(THREADS) void conv_igemm_kernel(
+    const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ bias,
+    float* __restrict__ out, ConvShape g, int relu)
+{
+    constexpr int TM = BM / 2, TN = BN / 2, FM = TM / 32, FN = TN / 32;
+    constexpr int A_FLOATS = KContigTile<BM>::FLOATS;
+    constexpr int B_PITCH = KStridedTile<BN>::PITCH;
+    constexpr int B_FLOATS = B_DGRAD ? KStridedTile<BN>::FLOATS : KContigTile<BN>::FLOATS;
+    constexpr int A_LOADS = BM / 64;                    // float4 loads per thread per K step
+    constexpr int B_LOADS = BN / 64;
+    __shared__ __attribute__((aligned(16))) float lds[2 * (A_FLOATS + B_FLOATS)];
+    float* As = lds;
+    float* Bs = lds + 2 * A_FLOATS;
+
+    const int M = g.N * g.Ho * g.Wo;
+    const int K = g.R * g.S * g.Ci;
+    const int tiles_n = (g.Co + BN - 1) / BN;
+    const unsigned tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (int)(tile / tiles_n) * BM, n0 = (int)(tile % tiles_n) * BN;
+    const int k_begin = blockIdx.z * g.k_per_split;
+    const int k_end = min(K, k_begin + g.k_per_split);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * TM, wn = (wave & 1) * TN;
+
+    // ---- per-thread gather coordinates of the A rows this thread stages (fixed over the K loop) ----
+    RowCoord rc[A_LOADS];
+    const int a_chunk = tid & 3;
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) {
+        const int m = m0 + (tid >> 2) + 64 * i;
+        rc[i].ok = m < M;
+        const int mm = rc[i].ok ? m : 0;
+        const int n = mm / (g.Ho * g.Wo), rem = mm - n * (g.Ho * g.Wo);
+        const int oy = rem / g.Wo, ox = rem - oy * g.Wo;
+        rc[i].base = n * g.Hi * g.Wi;
+        rc[i].iy0 = oy * g.stride - g.pad;
+        rc[i].ix0 = ox * g.stride - g.pad;
+    }
+
+    f32x4 a_reg[A_LOADS], b_reg[B_LOADS];
+    auto load_global = [&](int kt) {
+        // A: 4 consecutive lanes fetch the 64 contiguous bytes (16 channels) of one pixel tap
+        const int k0 = kt + a_chunk * 4;
+        const bool kok = k0 < k_end;
+        const int rs = kok ? k0 / g.Ci : 0;
+        const int c = k0 - rs * g.Ci;
+        const int r = rs / g.S, q = rs - r * g.S;
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) {
+            int ty = rc[i].iy0 + r, tx = rc[i].ix0 + q;
+            bool ok = kok && rc[i].ok && ty >= 0 && tx >= 0;
+            if (g.in_dil > 1) {
+                ok = ok && (ty % g.in_dil == 0) && (tx % g.in_dil == 0);
+                ty /= g.in_dil; tx /= g.in_dil;
+            }
+            ok = ok && ty < g.Hi && tx < g.Wi;
+            a_reg[i] = ok ? *reinterpret_cast<const f32x4*>(X + ((size_t)(rc[i].base + ty * g.Wi + tx)) * g.Ci + c)
+                          : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (!B_DGRAD) {
+            // B rows = output channels, K contiguous in the OHWI weight
+#pragma unroll
+            for (int i = 0; i < B_LOADS; ++i) {
+                const int n = n0 + (tid >> 2) + 64 * i;
+                b_reg[i] = (kok && n < g.Co) ? *reinterpret_cast<const f32x4*>(W + (size_t)n * K + k0)
+                                             : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        } else {
+            // B rows = k = (r,q,co) of the dgrad sum; columns = ci, contiguous in W[co][R-1-r][S-1-q][:]
+            // here g.Ci is the dY channel count (= weight Co) and g.Co the weight Ci
+#pragma unroll
+            for (int i = 0; i < B_LOADS; ++i) {
+                const int idx = tid + THREADS * i;             // BK rows x BN/4 chunks
+                const int kk = idx / (BN / 4), ch = idx - kk * (BN / 4);
+                const int k = kt + kk, n = n0 + ch * 4;
+                bool ok = k < k_end && n < g.Co;
+                const int rs2 = ok ? k / g.Ci : 0;
+                const int co = k - rs2 * g.Ci;
+                const int r2 = rs2 / g.S, q2 = rs2 - r2 * g.S;
+                b_reg[i] = ok ? *reinterpret_cast<const f32x4*>(
+                                    W + ((size_t)(co * g.R + (g.R - 1 - r2)) * g.S + (g.S - 1 - q2)) * g.Co + n)
+                              : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+    auto store_lds = [&](int buf) {
+        float* a = As + buf * A_FLOATS;
+        float* b = Bs + buf * B_FLOATS;
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i)
+            *reinterpret_cast<f32x4*>(a + ((tid >> 2) + 64 * i) * LDK + a_chunk * 4) = a_reg[i];
+        if (!B_DGRAD) {
+#pragma unroll
+            for (int i = 0; i < B_LOADS; ++i)
+                *reinterpret_cast<f32x4*>(b + ((tid >> 2) + 64 * i) * LDK + a_chunk * 4) = b_reg[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < B_LOADS; ++i) {
+                const int idx = tid + THREADS * i;
+                const int kk = idx / (BN / 4), ch = idx - kk * (BN / 4);
+                *reinterpret_cast<f32x4*>(b + kk * B_PITCH + ch * 4) = b_reg[i];
+            }
+        }
+    };
+
+    f32x16 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    if (k_begin < k_end) {
+        load_global(k_begin);
+        store_lds(0);
+        __syncthreads();
+        int buf = 0;
+        for (int kt = k_begin; kt < k_end; kt += BK) {
+            const bool more = kt + BK < k_end;
+            if (more) load_global(kt + BK);
+            float a[FM][8], b[FN][8];
+            read_kcontig<FM>(As + buf * A_FLOATS + wm * LDK, lane, a);
+            if (!B_DGRAD) read_kcontig<FN>(Bs + buf * B_FLOATS + wn * LDK, lane, b);
+            else read_kstrided<FN, B_PITCH>(Bs + buf * B_FLOATS + wn, lane, b);
+            mma_step<FM, FN>(a, b, acc);
+            if (more) store_lds(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+
+    // ---- epilogue: bias / relu, or raw partial sums when split-K --------------------------------
+    float* dst = out + (size_t)blockIdx.z * M * g.Co;
+    const bool final_pass = g.splits == 1;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        const int n = n0 + wn + j * 32 + frag_col(lane);
+        if (n >= g.Co) continue;
+        const float bv = (final_pass && bias) ? bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm + i * 32 + frag_row(lane, e);
+                if (m < M) {
+                    float v = acc[i][j][e] + bv;
+                    if (final_pass && relu) v = fmaxf(v, 0.f);
+                    dst[(size_t)m * g.Co + n] = v;
+                }
+            }
+    }
+}
+
+// out[i] = sum_z part[z][i] (+bias[i % ncols]) (relu)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                            const float* __restrict__ bias, long total4, int ncols,
+                                                            int splits, int relu, int accumulate)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total4) return;
+    f32x4 s = reinterpret_cast<const f32x4*>(part)[i];
+    for (int z = 1; z < splits; ++z) s += reinterpret_cast<const f32x4*>(part)[i + (long)z * total4];
+    if (bias) {
+        const int c = (int)((i * 4) % ncols);
+        s += *reinterpret_cast<const f32x4*>(bias + c);
+    }
+    if (relu) { s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f); }
+    if (accumulate) s += reinterpret_cast<const f32x4*>(out)[i];
+    reinterpret_cast<f32x4*>(out)[i] = s;
+}
+
+// ---- weight gradient -----------------------------------------------------------------------------
+struct WgradShape {
+    int N, Hi, Wi, Ci;       // forward input image X
+    int Ho, Wo, Co;          // forward output image (dY)
+    int R, S, stride, pad;
+    int splits, pix_per_split;   // multiple of BK
+};
+
+template <int BM, int BN>
+__global__ __launch_bounds__(THREADS) void conv_wgrad_kernel(
+    const float* __restrict__ dY, const float* __restrict__ X, float* __restrict__ out, WgradShape g)
+{
+    constexpr int TM = BM / 2, TN = BN / 2, FM = TM / 32, FN = TN / 32;
+    constexpr int A_PITCH = KStridedTile<BM>::PITCH, B_PITCH = KStridedTile<BN>::PITCH;
+    constexpr int A_FLOATS = KStridedTile<BM>::FLOATS, B_FLOATS = KStridedTile<BN>::FLOATS;
+    constexpr int A_LOADS = BM / 64, B_LOADS = BN / 64;      // BK*BM/4 float4 over 256 threads
+    __shared__ __attribute__((aligned(16))) float lds[2 * (A_FLOATS + B_FLOATS)];
+    float* As = lds;
+    float* Bs = lds + 2 * A_FLOATS;
+
+    const int NC = g.R * g.S * g.Ci;                         // GEMM N
+    const int P = g.N * g.Ho * g.Wo;                         // GEMM K (pixels)
+    const int tiles_n = (NC + BN - 1) / BN;
+    const unsigned tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (int)(tile / tiles_n) * BM, n0 = (int)(tile % tiles_n) * BN;
+    const int p_begin = blockIdx.z * g.pix_per_split, p_end = min(P, p_begin + g.pix_per_split);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * TM, wn = (wave & 1) * TN;
+
+    // column (r,q,c) of each B chunk this thread stages is fixed over the K loop
+    int b_kk[B_LOADS], b_col[B_LOADS], b_r[B_LOADS], b_q[B_LOADS], b_c[B_LOADS];
+    bool b_ok[B_LOADS];
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i) {
+        const int idx = tid + THREADS * i;
+        b_kk[i] = idx / (BN / 4);
+        b_col[i] = (idx - b_kk[i] * (BN / 4)) * 4;
+        const int col = n0 + b_col[i];
+        b_ok[i] = col < NC;
+        const int rs = b_ok[i] ? col / g.Ci : 0;
+        b_c[i] = col - rs * g.Ci;
+        b_r[i] = rs / g.S;
+        b_q[i] = rs - b_r[i] * g.S;
+    }
+
+    f32x4 a_reg[A_LOADS], b_reg[B_LOADS];
+    auto load_global = [&](int pt) {
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) {
+            const int idx = tid + THREADS * i;
+            const int kk = idx / (BM / 4), ch = (idx - kk * (BM / 4)) * 4;
+            const int p = pt + kk, co = m0 + ch;
+            a_reg[i] = (p < p_end && co < g.Co) ? *reinterpret_cast<const f32x4*>(dY + (size_t)p * g.Co + co)
+                                                : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i) {
+            const int p = pt + b_kk[i];
+            bool ok = b_ok[i] && p < p_end;
+            const int pp = ok ? p : 0;
+            const int n = pp / (g.Ho * g.Wo), rem = pp - n * (g.Ho * g.Wo);
+            const int oy = rem / g.Wo, ox = rem - oy * g.Wo;
+            const int iy = oy * g.stride - g.pad + b_r[i], ix = ox * g.stride - g.pad + b_q[i];
+            ok = ok && iy >= 0 && iy < g.Hi && ix >= 0 && ix < g.Wi;
+            b_reg[i] = ok ? *reinterpret_cast<const f32x4*>(X + ((size_t)(n * g.Hi + iy) * g.Wi + ix) * g.Ci + b_c[i])
+                          : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto store_lds = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) {
+            const int idx = tid + THREADS * i;
+            const int kk = idx / (BM / 4), ch = (idx - kk * (BM / 4)) * 4;
+            *reinterpret_cast<f32x4*>(As + buf * A_FLOATS + kk * A_PITCH + ch) = a_reg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i)
+            *reinterpret_cast<f32x4*>(Bs + buf * B_FLOATS + b_kk[i] * B_PITCH + b_col[i]) = b_reg[i];
+    };
+
+    f32x16 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    if (p_begin < p_end) {
+        load_global(p_begin);
+        store_lds(0);
+        __syncthreads();
+        int buf = 0;
+        for (int pt = p_begin; pt < p_end; pt += BK) {
+            const bool more = pt + BK < p_end;
+            if (more) load_global(pt + BK);
+            float a[FM][8], b[FN][8];
+            read_kstrided<FM, A_PITCH>(As + buf * A_FLOATS + wm, lane, a);
+            read_kstrided<FN, B_PITCH>(Bs + buf * B_FLOATS + wn, lane, b);
+            mma_step<FM, FN>(a, b, acc);
+            if (more) store_lds(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+    float* dst = out + (size_t)blockIdx.z * g.Co * NC;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        const int n = n0 + wn + j * 32 + frag_col(lane);
+        if (n >= NC) continue;
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm + i * 32 + frag_row(lane, e);
+                if (m < g.Co) dst[(size_t)m * NC + n] = acc[i][j][e];
+            }
+    }
+}
+
+// ---- stem helpers: NCHW (3 ch) -> NHWC padded to 4 channels; OHWI weight pad 3->4 and back -----------
+__global__ void nchw3_to_nhwc4_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int HW)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)N * HW) return;
+    const long n = i / HW, p = i - n * HW;
+    const float* s = x + n * 3 * (long)HW + p;
+    reinterpret_cast<f32x4*>(y)[i] = f32x4{s[0], s[HW], s[2 * (long)HW], 0.f};
+}
+
+__global__ void pad_channels_kernel(const float* __restrict__ src, float* __restrict__ dst, long rows, int cs, int cd)
+{
+    // dst[row][0..cd) = src[row][0..cs) zero-extended (cd > cs) or truncated (cd < cs)
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cd) return;
+    const long r = i / cd;
+    const int c = (int)(i - r * cd);
+    dst[i] = c < cs ? src[r * cs + c] : 0.f;
+}
+
+struct TileChoice { int bm, bn; };
+
+TileChoice pick_tile(long M, long N)
+{
+    // fill >= ~2 waves of workgroups over 256 CUs when the problem allows it, biggest tile first
+    const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
+    for (auto& c : cand) {
+        if (N <= 64 && c[1] == 128) continue;
+        if (ceil_div64(M, c[0]) * ceil_div64(N, c[1]) >= 512) return {c[0], c[1]};
+    }
+    if (N <= 64 || M > 4 * N) return {64, 64};
+    return {64, 64};
+}
+
+template <bool DGRAD>
+int launch_conv(const float* X, const float* W, const float* bias, float* out, float* workspace, size_t ws_bytes,
+                ConvShape g, int relu, hipStream_t st)
+{
+    const long M = (long)g.N * g.Ho * g.Wo;
+    const int K = g.R * g.S * g.Ci;
+    const TileChoice t = pick_tile(M, g.Co);
+    const long tiles = ceil_div64(M, t.bm) * ceil_div64(g.Co, t.bn);
+    // split K when the tile grid cannot fill the chip and K is long enough to amortise the reduce
+    int splits = 1;
+    if (workspace && tiles < 256) {
+        splits = (int)min((long)16, max((long)1, 512 / tiles));
+        while (splits > 1 && K / splits < 256) --splits;
+        while (splits > 1 && (size_t)splits * M * g.Co * sizeof(float) > ws_bytes) --splits;
+    }
+    const int ksteps = (K + BK - 1) / BK;
+    g.splits = splits;
+    g.k_per_split = ((ksteps + splits - 1) / splits) * BK;
+    float* dst = splits > 1 ? workspace : out;
+    dim3 grid((unsigned)tiles, 1, (unsigned)splits);
+#define PHNET_LAUNCH_CONV(BM_, BN_) \
+    hipLaunchKernelGGL((conv_igemm_kernel<BM_, BN_, DGRAD>), grid, dim3(THREADS), 0, st, X, W, bias, dst, g, relu)
+    if (t.bm == 128 && t.bn == 128) PHNET_LAUNCH_CONV(128, 128);
+    else if (t.bm == 128 && t.bn == 64) PHNET_LAUNCH_CONV(128, 64);
+    else if (t.bm == 64 && t.bn == 128) PHNET_LAUNCH_CONV(64, 128);
+    else PHNET_LAUNCH_CONV(64, 64);
+#undef PHNET_LAUNCH_CONV
+    if (splits > 1) {
+        const long total4 = M * g.Co / 4;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)ceil_div64(total4, 256)), dim3(256), 0, st,
+                           workspace, out, bias, total4, g.Co, splits, relu, 0);
+    }
+    return phnet_launch_status();
+}
+
+}  // namespace
+
+// Forward convolution / linear.  x NHWC [N][Hi][Wi][Ci], w OHWI [Co][R][S][Ci], bias [Co] or NULL,
+// y NHWC [N][Ho][Wo][Co].  Ci % 4 == 0, Co % 4 == 0.  workspace (optional, for split-K) is caller-allocated.
+PHNET_API int phnet_conv2d_fwd(const float* x, const float* w, const float* bias, float* y,
+                               int32_t N, int32_t Hi, int32_t Wi, int32_t Ci, int32_t Co, int32_t R, int32_t S,
+                               int32_t stride, int32_t pad, int32_t relu,
+                               void* workspace, uint64_t ws_bytes, void* stream)
+{
+    if (N < 0 || Hi < 1 || Wi < 1 || Ci < 4 || Co < 4 || (Ci & 3) || (Co & 3) || R < 1 || S < 1 || stride < 1 || pad < 0)
+        return PHNET_ERR_ARG;
+    if (N == 0) return PHNET_OK;
+    if (!x || !w || !y) return PHNET_ERR_ARG;
+    ConvShape g{};
+    g.N = N; g.Hi = Hi; g.Wi = Wi; g.Ci = Ci; g.Co = Co; g.R = R; g.S = S;
+    g.Ho = (Hi + 2 * pad - R) / stride + 1;
+    g.Wo = (Wi + 2 * pad - S) / stride + 1;
+    if (g.Ho < 1 || g.Wo < 1) return PHNET_ERR_ARG;
+    g.stride = stride; g.pad = pad; g.in_dil = 1;
+    return launch_conv<false>(x, w, bias, y, (float*)workspace, ws_bytes, g, relu, (hipStream_t)stream);
+}
+
+// Data gradient.  dy NHWC [N][Ho][Wo][Co], w OHWI [Co][R][S][Ci] (as used by the forward), dx NHWC [N][Hi][Wi][Ci].
+PHNET_API int phnet_conv2d_dgrad(const float* dy, const float* w, float* dx,
+                                 int32_t N, int32_t Hi, int32_t Wi, int32_t Ci, int32_t Co, int32_t R, int32_t S,
+                                 int32_t stride, int32_t pad, void* workspace, uint64_t ws_bytes, void* stream)
+{
+    if (N < 0 || Hi < 1 || Wi < 1 || Ci < 4 || Co < 4 || (Ci & 3) || (Co & 3) || R < 1 || S < 1 || stride < 1 || pad < 0)
+        return PHNET_ERR_ARG;
+    if (N == 0) return PHNET_OK;
+    if (!dy || !w || !dx) return PHNET_ERR_ARG;
+    ConvShape g{};
+    g.N = N;
+    g.Hi = (Hi + 2 * pad - R) / stride + 1;      // A-side image = dY
+    g.Wi = (Wi + 2 * pad - S) / stride + 1;
+    g.Ci = Co;
+    g.Ho = Hi; g.Wo = Wi; g.Co = Ci;              // GEMM output = dX
+    g.R = R; g.S = S;
+    g.stride = 1; g.pad = R - 1 - pad; g.in_dil = stride;
+    if (R != S && (S - 1 - pad) != g.pad) return PHNET_ERR_ARG;   // square padding only
+    if (g.pad < 0) return PHNET_ERR_ARG;
+    return launch_conv<true>(dy, w, nullptr, dx, (float*)workspace, ws_bytes, g, 0, (hipStream_t)stream);
+}
+
+// Weight gradient.  dw OHWI [Co][R][S][Ci] is overwritten (accumulate=0) or added to (accumulate=1).
+// workspace must hold splits*Co*R*S*Ci floats; query with phnet_conv2d_wgrad_workspace.
+static long wgrad_splits(long P, long Co, long NC, int* bm_out)
+{
+    const int bm = Co >= 128 ? 128 : 64;
+    const long tiles = ceil_div64(Co, bm) * ceil_div64(NC, 64);
+    long splits = max((long)1, min((long)256, 768 / max((long)1, tiles)));
+    splits = max((long)1, min(splits, P / 64));
+    if (bm_out) *bm_out = bm;
+    return splits;
+}
+
+PHNET_API uint64_t phnet_conv2d_wgrad_workspace(int32_t N, int32_t Hi, int32_t Wi, int32_t Ci, int32_t Co,
+                                                int32_t R, int32_t S, int32_t stride, int32_t pad)
+{
+    const long Ho = (Hi + 2 * pad - R) / stride + 1, Wo = (Wi + 2 * pad - S) / stride + 1;
+    const long P = (long)N * Ho * Wo, NC = (long)R * S * Ci;
+    return (uint64_t)(wgrad_splits(P, Co, NC, nullptr) * Co * NC * sizeof(float));
+}
+
+PHNET_API int phnet_conv2d_wgrad(const float* dy, const float* x, float* dw,
+                                 int32_t N, int32_t Hi, int32_t Wi, int32_t Ci, int32_t Co, int32_t R, int32_t S,
+                                 int32_t stride, int32_t pad, int32_t accumulate,
+                                 void* workspace, uint64_t ws_bytes, void* stream)
+{
+    if (N < 0 || Hi < 1 || Wi < 1 || Ci < 4 || Co < 4 || (Ci & 3) || (Co & 3) || R < 1 || S < 1 || stride < 1 || pad < 0)
+        return PHNET_ERR_ARG;
+    if (!dy || !x || !dw) return PHNET_ERR_ARG;
+    WgradShape g{};
+    g.N = N; g.Hi = Hi; g.Wi = Wi; g.Ci = Ci; g.Co = Co; g.R = R; g.S = S; g.stride = stride; g.pad = pad;
+    g.Ho = (Hi + 2 * pad - R) / stride + 1;
+    g.Wo = (Wi + 2 * pad - S) / stride + 1;
+    const long P = (long)N * g.Ho * g.Wo, NC = (long)R * S * Ci;
+    hipStream_t st = (hipStream_t)stream;
+    int bm = 64;
+    const int bn = 64;
+    long splits = wgrad_splits(P, Co, NC, &bm);
+    const long tiles = ceil_div64(Co, bm) * ceil_div64(NC, bn);
+    while (splits > 1 && (uint64_t)(splits * Co * NC * sizeof(float)) > ws_bytes) --splits;
+    if (!workspace || (uint64_t)(splits * Co * NC * sizeof(float)) > ws_bytes) return PHNET_ERR_WORKSPACE;
+    const long psteps = ceil_div64(max(P, (long)1), BK);
+    g.splits = (int)splits;
+    g.pix_per_split = (int)(ceil_div64(psteps, splits) * BK);
+    dim3 grid((unsigned)tiles, 1, (unsigned)splits);
+    if (bm == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, 64>), grid, dim3(THREADS), 0, st, dy, x, (float*)workspace, g);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<64, 64>), grid, dim3(THREADS), 0, st, dy, x, (float*)workspace, g);
+    const long total4 = (long)Co * NC / 4;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)ceil_div64(total4, 256)), dim3(256), 0, st,
+                       (const float*)workspace, dw, (const float*)nullptr, total4, (int)NC, (int)splits, 0, accumulate);
+    return phnet_launch_status();
+}
+
+// x NCHW [N][3][H][W] -> y NHWC [N][H][W][4] (4th channel zero): feeds the 7x7 stem.
+PHNET_API int phnet_nchw3_to_nhwc4(const float* x, float* y, int32_t N, int32_t H, int32_t W, void* stream)
+{
+    if (N < 0 || H < 1 || W < 1) return PHNET_ERR_ARG;
+    if (N == 0) return PHNET_OK;
+    if (!x || !y) return PHNET_ERR_ARG;
+    const long total = (long)N * H * W;
+    hipLaunchKernelGGL(nchw3_to_nhwc4_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       x, y, N, H * W);
+    return phnet_launch_status();
+}
+
+// dst[rows][cd] <- src[rows][cs], zero-extending or truncating the innermost dimension.
+PHNET_API int phnet_pad_channels(const float* src, float* dst, int64_t rows, int32_t cs, int32_t cd, void* stream)
+{
+    if (rows < 0 || cs < 1 || cd < 1) return PHNET_ERR_ARG;
+    if (rows == 0) return PHNET_OK;
+    if (!src || !dst) return PHNET_ERR_ARG;
+    hipLaunchKernelGGL(pad_channels_kernel, dim3((unsigned)ceil_div64(rows * cd, 256)), dim3(256), 0, (hipStream_t)stream,
+                       src, dst, (long)rows, cs, cd);
+    return phnet_launch_status();
+}

@@ -1,0 +1,80 @@
+// fp32 MFMA implicit-GEMM building blocks for gfx950 (CDNA4), shared by conv.hip and gemm.hip.
+//
+// Arithmetic: v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate: bit-for-bit an fmaf chain; dense peak
+// 157.3 TF/s = 64 FLOP/clk/SIMD).  The reference runs this path in fp32 end to end
+// (trainOL.py:21-22,225: GradScaler without autocast), so f32-input MFMA keeps its numerics.
+//
+// Tiling: 256 threads = 4 wavefronts in a 2x2 arrangement; block tile BM x BN (64 or 128 each), wave
+// tile (BM/2) x (BN/2) made of 32x32 MFMA fragments; K step 16, double-buffered in LDS with register
+// prefetch of the next step (one barrier per step).
+//
+// LDS images (conflict-free by construction, see MI355X_MICROARCH.md "LDS"):
+//   K-contiguous operand ([row][k]: im2col rows, [N][K] weights): [rows][20] floats; the fill is one
+//     ds_write_b128 per 4 k's, the fragment read is 2 x ds_read_b128 per 32-row fragment and K step
+//     (80-byte row pitch -> the 16 lanes of a b128 lane group hit 16 distinct 4-bank slots).
+//   K-strided operand ([k][col]: dY for wgrad, [K][N] right-hand sides): [16][cols+4] floats; fill is
+//     ds_write_b128 along the columns, fragment read is ds_read_b32 (32 consecutive floats per half wave).
+// The MFMA k index of (lane half h, step s) is 8h+s for BOTH operands, which is what lets the
+// K-contiguous image be read with 128-bit loads.
+#pragma once
+#include "common.h"
+
+namespace igemm {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BK = 16;
+constexpr int LDK = 20;          // row pitch (floats) of a K-contiguous LDS image
+constexpr int THREADS = 256;
+
+template <int ROWS> struct KContigTile { static constexpr int FLOATS = ROWS * LDK; };
+template <int COLS> struct KStridedTile { static constexpr int PITCH = COLS + 4; static constexpr int FLOATS = BK * PITCH; };
+
+// ---- fragment reads ---------------------------------------------------------------------------
+// K-contiguous image: fragment f covers rows [32f, 32f+32) of the wave's sub-tile.
+template <int F>
+__device__ __forceinline__ void read_kcontig(const float* tile, int lane, float (&frag)[F][8]) {
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+        const f32x4* p = reinterpret_cast<const f32x4*>(tile + (f * 32 + r) * LDK + 8 * h);
+        const f32x4 lo = p[0], hi = p[1];
+        frag[f][0] = lo.x; frag[f][1] = lo.y; frag[f][2] = lo.z; frag[f][3] = lo.w;
+        frag[f][4] = hi.x; frag[f][5] = hi.y; frag[f][6] = hi.z; frag[f][7] = hi.w;
+    }
+}
+
+// K-strided image: column c of fragment f, k = 8h+s.
+template <int F, int PITCH>
+__device__ __forceinline__ void read_kstrided(const float* tile, int lane, float (&frag)[F][8]) {
+    const int c = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int f = 0; f < F; ++f)
+#pragma unroll
+        for (int s = 0; s < 8; ++s) frag[f][s] = tile[(8 * h + s) * PITCH + f * 32 + c];
+}
+
+template <int FM, int FN>
+__device__ __forceinline__ void mma_step(const float (&a)[FM][8], const float (&b)[FN][8], f32x16 (&acc)[FM][FN]) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+}
+
+// C/D fragment element `reg` of lane `lane` sits at (row, col) of the 32x32 tile:
+__device__ __forceinline__ int frag_row(int lane, int reg) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+__device__ __forceinline__ int frag_col(int lane) { return lane & 31; }
+
+// XCD-aware bijective remap (cdna_hip_programming.md 5, "XCD swizzle must be bijective"): blocks that
+// are neighbours in the logical tile order land on the same XCD (= same L2).
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblocks) {
+    const unsigned xcd = bid & 7u, q = nblocks >> 3, r = nblocks & 7u;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+}  // namespace igemm

@@ -1,0 +1,254 @@
+"""Tensor-level wrappers over the C-ABI (include/phnet_hip.h): shape checks, output allocation, stream plumbing.
+
+PyTorch is used here only for device memory and the current HIP stream.  No op in this file has a
+fallback: a non-CUDA tensor or a missing library raises.
+"""
+from typing import Optional, Tuple
+
+import torch
+
+from ._lib import check, lib
+
+_WS = {}
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _req(t: torch.Tensor, dtype=torch.float32, name="tensor"):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA(HIP) tensor; phnet_amd has no CPU path")
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+    return t
+
+
+def workspace(nbytes: int, device, slot: int = 0) -> torch.Tensor:
+    """Grow-only scratch buffer per (device, slot).  Kernels on one stream serialise, so sharing is safe."""
+    key = (torch.device(device).index, slot)
+    cur = _WS.get(key)
+    if cur is None or cur.numel() < nbytes:
+        cur = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _WS[key] = cur
+    return cur
+
+
+# ------------------------------------------------------------------------------------------------ NMS
+def lane_nms(rows: torch.Tensor, scores: torch.Tensor, thresh: float, top_k: int,
+             counts: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """rows [K,5+S] or [F,K,5+S]; returns (keep, num_to_keep, parent) shaped like the reference's outputs."""
+    _req(rows, name="rows"); _req(scores, name="scores")
+    batched = rows.dim() == 3
+    f = rows.shape[0] if batched else 1
+    k, prop = rows.shape[-2], rows.shape[-1]
+    if scores.numel() != f * k:
+        raise RuntimeError("scores must have one entry per row")
+    if counts is not None:
+        _req(counts, torch.int32, "counts")
+    keep = torch.empty((f, k), dtype=torch.int64, device=rows.device)
+    parent = torch.empty((f, k), dtype=torch.int64, device=rows.device)
+    num = torch.empty((f,), dtype=torch.int64, device=rows.device)
+    check(lib().phnet_lane_nms(_ptr(rows), _ptr(scores), _ptr(counts), f, k, prop - 5, float(thresh), int(top_k),
+                               _ptr(keep), _ptr(num), _ptr(parent), _stream()), "phnet_lane_nms")
+    if batched:
+        return keep, num, parent
+    return keep[0], num[0], parent[0]
+
+
+# ------------------------------------------------------------------------------------------------ ROI pooling
+def roi_pool_fwd(fmap: torch.Tensor, xs: torch.Tensor, ys: torch.Tensor) -> torch.Tensor:
+    """fmap [B,h,w,64] NHWC, xs [B,N,P], ys [P] -> [B,N,P,64]."""
+    _req(fmap, name="fmap"); _req(xs, name="xs"); _req(ys, name="ys")
+    b, h, w, c = fmap.shape
+    _, n, p = xs.shape
+    out = torch.empty((b, n, p, c), dtype=torch.float32, device=fmap.device)
+    check(lib().phnet_roi_pool_fwd(_ptr(fmap), _ptr(xs), _ptr(ys), _ptr(out), b, n, p, h, w, c, _stream()), "phnet_roi_pool_fwd")
+    return out
+
+
+def roi_pool_bwd(dout, fmap, xs, ys, dmap: Optional[torch.Tensor], need_dxs: bool):
+    _req(dout, name="dout")
+    b, h, w, c = fmap.shape
+    _, n, p = xs.shape
+    dxs = torch.empty_like(xs) if need_dxs else None
+    check(lib().phnet_roi_pool_bwd(_ptr(dout), _ptr(fmap), _ptr(xs), _ptr(ys), _ptr(dmap), _ptr(dxs),
+                                   b, n, p, h, w, c, _stream()), "phnet_roi_pool_bwd")
+    return dxs
+
+
+# ------------------------------------------------------------------------------------------------ conv / linear
+def conv_out_hw(hi, wi, r, s, stride, pad):
+    return (hi + 2 * pad - r) // stride + 1, (wi + 2 * pad - s) // stride + 1
+
+
+def conv2d_fwd(x, w, bias, stride: int, pad: int, relu: bool = False, out: Optional[torch.Tensor] = None):
+    """x NHWC [N,Hi,Wi,Ci]; w OHWI [Co,R,S,Ci]; -> NHWC [N,Ho,Wo,Co]."""
+    _req(x, name="x"); _req(w, name="w")
+    n, hi, wi, ci = x.shape
+    co, r, s, ci2 = w.shape
+    assert ci == ci2, (x.shape, w.shape)
+    ho, wo = conv_out_hw(hi, wi, r, s, stride, pad)
+    if out is None:
+        out = torch.empty((n, ho, wo, co), dtype=torch.float32, device=x.device)
+    ws = workspace(16 * n * ho * wo * co * 4 if n * ho * wo * co < (1 << 22) else 0, x.device)
+    check(lib().phnet_conv2d_fwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(out), n, hi, wi, ci, co, r, s, stride, pad,
+                                 int(relu), _ptr(ws), ws.numel(), _stream()), "phnet_conv2d_fwd")
+    return out
+
+
+def conv2d_dgrad(dy, w, in_hw: Tuple[int, int], stride: int, pad: int):
+    _req(dy, name="dy"); _req(w, name="w")
+    n = dy.shape[0]
+    co, r, s, ci = w.shape
+    hi, wi = in_hw
+    dx = torch.empty((n, hi, wi, ci), dtype=torch.float32, device=dy.device)
+    ws = workspace(16 * n * hi * wi * ci * 4 if n * hi * wi * ci < (1 << 22) else 0, dy.device)
+    check(lib().phnet_conv2d_dgrad(_ptr(dy), _ptr(w), _ptr(dx), n, hi, wi, ci, co, r, s, stride, pad,
+                                   _ptr(ws), ws.numel(), _stream()), "phnet_conv2d_dgrad")
+    return dx
+
+
+def conv2d_wgrad(dy, x, w_shape, stride: int, pad: int, dw: Optional[torch.Tensor] = None, accumulate: bool = False):
+    _req(dy, name="dy"); _req(x, name="x")
+    n, hi, wi, ci = x.shape
+    co, r, s, _ = w_shape
+    if dw is None:
+        dw = torch.empty((co, r, s, ci), dtype=torch.float32, device=x.device)
+        accumulate = False
+    need = lib().phnet_conv2d_wgrad_workspace(n, hi, wi, ci, co, r, s, stride, pad)
+    ws = workspace(need, x.device)
+    check(lib().phnet_conv2d_wgrad(_ptr(dy), _ptr(x), _ptr(dw), n, hi, wi, ci, co, r, s, stride, pad, int(accumulate),
+                                   _ptr(ws), ws.numel(), _stream()), "phnet_conv2d_wgrad")
+    return dw
+
+
+def linear_fwd(x2d, w, bias, relu: bool = False):
+    """x [M,K], w [N,K] -> [M,N] (= conv 1x1 on an [M,1,1,K] image)."""
+    m, k = x2d.shape
+    return conv2d_fwd(x2d.view(m, 1, 1, k), w.view(w.shape[0], 1, 1, k), bias, 1, 0, relu).view(m, w.shape[0])
+
+
+def linear_dgrad(dy2d, w):
+    m, n = dy2d.shape
+    k = w.shape[1]
+    return conv2d_dgrad(dy2d.view(m, 1, 1, n), w.view(n, 1, 1, k), (1, 1), 1, 0).view(m, k)
+
+
+def linear_wgrad(dy2d, x2d, dw: Optional[torch.Tensor] = None, accumulate: bool = False):
+    m, n = dy2d.shape
+    k = x2d.shape[1]
+    out = conv2d_wgrad(dy2d.view(m, 1, 1, n), x2d.view(m, 1, 1, k), (n, 1, 1, k), 1, 0,
+                       None if dw is None else dw.view(n, 1, 1, k), accumulate)
+    return out.view(n, k)
+
+
+def nchw3_to_nhwc4(x):
+    _req(x, name="frames")
+    n, c, h, w = x.shape
+    assert c == 3
+    y = torch.empty((n, h, w, 4), dtype=torch.float32, device=x.device)
+    check(lib().phnet_nchw3_to_nhwc4(_ptr(x), _ptr(y), n, h, w, _stream()), "phnet_nchw3_to_nhwc4")
+    return y
+
+
+def pad_channels(src2d, cd: int):
+    _req(src2d, name="src")
+    rows, cs = src2d.shape
+    dst = torch.empty((rows, cd), dtype=torch.float32, device=src2d.device)
+    check(lib().phnet_pad_channels(_ptr(src2d), _ptr(dst), rows, cs, cd, _stream()), "phnet_pad_channels")
+    return dst
+
+
+# ------------------------------------------------------------------------------------------------ BN / pool / FPN
+def _partials(m, c, device, slot=1):
+    nfloats = lib().phnet_channel_partials_size(m, c)
+    return workspace(nfloats * 4, device, slot)
+
+
+def bn_fwd(x, gamma, beta, running_mean, running_var, training: bool, eps: float, momentum: float,
+           residual=None, relu: bool = True):
+    """x [..., C] NHWC conv output.  Returns (y, save_mean, save_invstd); stats tensors are None in eval."""
+    _req(x, name="x")
+    c = x.shape[-1]
+    m = x.numel() // c
+    dev = x.device
+    scale = torch.empty(c, dtype=torch.float32, device=dev)
+    shift = torch.empty(c, dtype=torch.float32, device=dev)
+    sm = torch.empty(c, dtype=torch.float32, device=dev) if training else None
+    si = torch.empty(c, dtype=torch.float32, device=dev) if training else None
+    part = _partials(m, c, dev) if training else None
+    check(lib().phnet_bn_fwd_stats(_ptr(x), m, c, eps, momentum, _ptr(gamma), _ptr(beta), _ptr(running_mean),
+                                   _ptr(running_var), _ptr(sm), _ptr(si), _ptr(scale), _ptr(shift), _ptr(part),
+                                   int(training), _stream()), "phnet_bn_fwd_stats")
+    y = torch.empty_like(x)
+    check(lib().phnet_bn_apply(_ptr(x), _ptr(scale), _ptr(shift), _ptr(residual), _ptr(y), m, c, int(relu), _stream()),
+          "phnet_bn_apply")
+    return y, sm, si
+
+
+def bn_bwd(dy, x, y, save_mean, save_invstd, gamma, relu: bool, dres: Optional[torch.Tensor] = None,
+           dres_accumulate: bool = False):
+    """Returns (dx, dgamma, dbeta); writes/accumulates the residual-branch gradient into dres when given."""
+    _req(dy, name="dy")
+    c = x.shape[-1]
+    m = x.numel() // c
+    dev = x.device
+    dx = torch.empty_like(x)
+    dgamma = torch.empty(c, dtype=torch.float32, device=dev)
+    dbeta = torch.empty(c, dtype=torch.float32, device=dev)
+    c12 = torch.empty(2, c, dtype=torch.float32, device=dev)
+    part = _partials(m, c, dev)
+    check(lib().phnet_bn_bwd(_ptr(dy), _ptr(x), _ptr(y), _ptr(save_mean), _ptr(save_invstd), _ptr(gamma), _ptr(dx),
+                             _ptr(dres), _ptr(dgamma), _ptr(dbeta), _ptr(part), _ptr(c12[0]), _ptr(c12[1]),
+                             m, c, int(relu), int(dres_accumulate), 0, _stream()), "phnet_bn_bwd")
+    return dx, dgamma, dbeta
+
+
+def maxpool_fwd(x):
+    _req(x, name="x")
+    n, hi, wi, c = x.shape
+    ho, wo = (hi - 1) // 2 + 1, (wi - 1) // 2 + 1
+    y = torch.empty((n, ho, wo, c), dtype=torch.float32, device=x.device)
+    arg = torch.empty((n, ho, wo, c), dtype=torch.uint8, device=x.device)
+    check(lib().phnet_maxpool3x3s2_fwd(_ptr(x), _ptr(y), _ptr(arg), n, hi, wi, c, _stream()), "phnet_maxpool3x3s2_fwd")
+    return y, arg
+
+
+def maxpool_bwd(dy, arg, in_shape):
+    n, hi, wi, c = in_shape
+    dx = torch.empty(in_shape, dtype=torch.float32, device=dy.device)
+    check(lib().phnet_maxpool3x3s2_bwd(_ptr(_req(dy)), _ptr(arg), _ptr(dx), n, hi, wi, c, _stream()), "phnet_maxpool3x3s2_bwd")
+    return dx
+
+
+def upsample_add_(fine, coarse):
+    n, H, W, c = fine.shape
+    _, h, w, _ = coarse.shape
+    check(lib().phnet_upsample_add(_ptr(_req(fine)), _ptr(_req(coarse)), n, H, W, h, w, c, _stream()), "phnet_upsample_add")
+    return fine
+
+
+def upsample_add_bwd_(dfine, dcoarse):
+    n, H, W, c = dfine.shape
+    _, h, w, _ = dcoarse.shape
+    check(lib().phnet_upsample_add_bwd(_ptr(_req(dfine)), _ptr(_req(dcoarse)), n, H, W, h, w, c, _stream()),
+          "phnet_upsample_add_bwd")
+    return dcoarse
+
+
+def colsum(a2d, out: Optional[torch.Tensor] = None, accumulate: bool = False):
+    _req(a2d, name="a")
+    m, c = a2d.shape
+    if out is None:
+        out = torch.empty(c, dtype=torch.float32, device=a2d.device)
+        accumulate = False
+    ws = workspace(lib().phnet_colsum_workspace(m, c), a2d.device, 2)
+    check(lib().phnet_colsum(_ptr(a2d), _ptr(out), m, c, int(accumulate), _ptr(ws), ws.numel(), _stream()), "phnet_colsum")
+    return out

@@ -1,0 +1,232 @@
+"""Per-kernel parity on a real MI355X: every C-ABI entry point against a plain PyTorch fp64/fp32 CPU
+statement of the same op (and the NMS against the CPU oracle, bit-exact).  Run with -m gpu."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from phnet_amd import hip_ops
+    return hip_ops
+
+
+def dev(t):
+    return t.to("cuda").contiguous()
+
+
+def nhwc(t):   # NCHW cpu -> NHWC cuda
+    return t.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+def close(a, b, tol=2e-4):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    scale = max(1.0, float(b.abs().max()))
+    err = float((a - b).abs().max())
+    assert err <= tol * scale, (err, scale)
+
+
+# ------------------------------------------------------------------------------------------------ NMS
+def _random_lanes(K, n_off, seed):
+    r = np.random.default_rng(seed)
+    rows = np.zeros((K, 5 + n_off), np.float32)
+    base = r.uniform(0, 800, (K, 1)) + r.normal(0, 12, (K, n_off)).cumsum(1)
+    if K > 1:
+        base[K // 2:] = base[:K - K // 2] + r.normal(0, 30, (K - K // 2, 1))
+    rows[:, 5:] = base
+    rows[:, 2] = r.uniform(-0.3, 1.2, K)
+    rows[:, 4] = r.uniform(-2, 40, K)
+    scores = (r.permutation(K).astype(np.float32) + 0.5) / K
+    return rows, scores
+
+
+@pytest.mark.parametrize("K,n_off,top_k", [(1, 36, 4), (2, 36, 4), (63, 36, 4), (64, 36, 4), (65, 36, 4), (240, 36, 4),
+                                           (240, 36, 1000), (240, 72, 4), (500, 36, 7), (700, 72, 3)])
+def test_lane_nms_bit_exact_vs_oracle(ops, K, n_off, top_k):
+    from oracle import lane_nms as ON
+    rows, scores = _random_lanes(K, n_off, K + n_off)
+    keep, num, parent = ops.lane_nms(dev(torch.from_numpy(rows)), dev(torch.from_numpy(scores)), 50.0, top_k)
+    rk, rn, rp = ON.lane_nms(rows, scores, 50.0, top_k)
+    assert int(num) == rn
+    assert keep.cpu().numpy().tolist() == rk.tolist()
+    assert parent.cpu().numpy().tolist() == rp.tolist()
+
+
+def test_lane_nms_batched_ragged_counts(ops):
+    from oracle import lane_nms as ON
+    F_, K = 6, 240
+    counts = [240, 0, 1, 100, 64, 239]
+    rows = np.zeros((F_, K, 41), np.float32); scores = np.zeros((F_, K), np.float32)
+    for f in range(F_):
+        rows[f], scores[f] = _random_lanes(K, 36, 100 + f)
+    keep, num, parent = ops.lane_nms(dev(torch.from_numpy(rows)), dev(torch.from_numpy(scores)), 50.0, 4,
+                                     counts=torch.tensor(counts, dtype=torch.int32, device="cuda"))
+    for f, c in enumerate(counts):
+        rk, rn, rp = ON.lane_nms(rows[f, :c], scores[f, :c], 50.0, 4)
+        assert int(num[f]) == rn
+        assert keep[f, :c].cpu().numpy().tolist() == rk.tolist()
+        assert parent[f, :c].cpu().numpy().tolist() == rp.tolist()
+
+
+def test_lane_nms_empty(ops):
+    keep, num, parent = ops.lane_nms(torch.zeros(0, 41, device="cuda"), torch.zeros(0, device="cuda"), 50.0, 4)
+    assert int(num) == 0 and keep.numel() == 0
+
+
+# ------------------------------------------------------------------------------------------------ ROI pooling
+@pytest.mark.parametrize("h,w", [(10, 25), (20, 50), (40, 100), (2, 5)])
+def test_roi_pool_fwd_bwd_vs_grid_sample(ops, h, w):
+    torch.manual_seed(h * w)
+    B, N, P, C = 1, 240, 36, 64
+    fmap = torch.randn(B, C, h, w, dtype=torch.float64, requires_grad=True)
+    xs = (torch.rand(B, N, P, dtype=torch.float64) * 1.6 - 0.3).requires_grad_(True)   # some anchors leave the map
+    ys = torch.flip(1 - torch.arange(P, dtype=torch.float64) / (P - 1), dims=[0])
+    gx = torch.flip(xs, dims=[2]) * 2 - 1
+    gy = (ys * 2 - 1).view(1, 1, P).expand(B, N, P)
+    ref = F.grid_sample(fmap, torch.stack([gx, gy], -1), align_corners=True).permute(0, 2, 3, 1)    # [B,N,P,C]
+    gout = torch.randn_like(ref)
+    ref.backward(gout)
+    out = ops.roi_pool_fwd(nhwc(fmap.detach().float()), dev(xs.detach().float()), dev(ys.float()))
+    close(out, ref, 1e-5)
+    dmap = torch.zeros(B, h, w, C, device="cuda")
+    dxs = ops.roi_pool_bwd(dev(gout.float()), nhwc(fmap.detach().float()), dev(xs.detach().float()), dev(ys.float()), dmap, True)
+    close(dmap, fmap.grad.permute(0, 2, 3, 1), 1e-4)
+    close(dxs, xs.grad, 1e-4)
+
+
+# ------------------------------------------------------------------------------------------------ conv / linear
+CONV_CASES = [
+    # N, Hi, Wi, Ci, Co, R, stride, pad
+    (2, 16, 20, 64, 64, 3, 1, 1),
+    (5, 20, 50, 64, 128, 3, 2, 1),
+    (2, 20, 50, 64, 128, 1, 2, 0),
+    (1, 10, 25, 512, 512, 3, 1, 1),        # split-K path (few tiles, long K)
+    (2, 33, 47, 4, 64, 7, 2, 3),           # stem geometry (3 channels padded to 4), ragged sizes
+    (3, 9, 13, 128, 64, 1, 1, 0),
+    (1, 80, 200, 64, 64, 3, 1, 1),         # 128x64 tile path
+    (240, 1, 1, 1024, 8192, 1, 1, 0),      # hyper-net linear
+    (240, 1, 1, 4608, 1024, 1, 1, 0),      # long-K linear -> split-K
+    (240, 1, 1, 64, 36, 1, 1, 0),          # ragged Co (36 offsets)
+    (7, 1, 1, 128, 4, 1, 1, 0),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(ops, case):
+    N, Hi, Wi, Ci, Co, R, stride, pad = case
+    torch.manual_seed(sum(case))
+    x = torch.randn(N, Ci, Hi, Wi, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn(Co, Ci, R, R, dtype=torch.float64) / (Ci * R * R) ** 0.5).requires_grad_(True)
+    b = torch.randn(Co, dtype=torch.float64)
+    ref = F.conv2d(x, w, b, stride=stride, padding=pad)
+    gy = torch.randn_like(ref)
+    ref.backward(gy)
+    xd, wd = nhwc(x.detach().float()), nhwc(w.detach().float())
+    y = ops.conv2d_fwd(xd, wd, dev(b.float()), stride, pad)
+    close(y, ref.permute(0, 2, 3, 1), 2e-5)
+    yr = ops.conv2d_fwd(xd, wd, dev(b.float()), stride, pad, relu=True)
+    close(yr, F.relu(ref).permute(0, 2, 3, 1), 2e-5)
+    gyd = nhwc(gy.float())
+    dx = ops.conv2d_dgrad(gyd, wd, (Hi, Wi), stride, pad)
+    close(dx, x.grad.permute(0, 2, 3, 1), 2e-5)
+    dw = ops.conv2d_wgrad(gyd, xd, wd.shape, stride, pad)
+    close(dw, w.grad.permute(0, 2, 3, 1), 2e-5)
+    dw2 = ops.conv2d_wgrad(gyd, xd, wd.shape, stride, pad, dw=dw.clone(), accumulate=True)
+    close(dw2, 2 * w.grad.permute(0, 2, 3, 1), 2e-5)
+
+
+def test_linear_wrappers(ops):
+    torch.manual_seed(1)
+    x = torch.randn(240, 2304, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn(576, 2304, dtype=torch.float64) / 48).requires_grad_(True)
+    b = torch.randn(576, dtype=torch.float64)
+    ref = F.linear(x, w, b)
+    g = torch.randn_like(ref)
+    ref.backward(g)
+    close(ops.linear_fwd(dev(x.detach().float()), dev(w.detach().float()), dev(b.float())), ref, 2e-5)
+    close(ops.linear_dgrad(dev(g.float()), dev(w.detach().float())), x.grad, 2e-5)
+    close(ops.linear_wgrad(dev(g.float()), dev(x.detach().float())), w.grad, 2e-5)
+    close(ops.colsum(dev(g.float())), g.sum(0), 2e-5)
+
+
+def test_stem_layout_helpers(ops):
+    x = torch.randn(3, 3, 17, 23)
+    y = ops.nchw3_to_nhwc4(dev(x))
+    assert torch.equal(y[..., :3].cpu(), x.permute(0, 2, 3, 1)) and float(y[..., 3].abs().max()) == 0.0
+    w = torch.randn(64 * 49, 3)
+    p = ops.pad_channels(dev(w), 4)
+    assert torch.equal(p[:, :3].cpu(), w) and float(p[:, 3].abs().max()) == 0.0
+    assert torch.equal(ops.pad_channels(p, 3).cpu(), w)
+
+
+# ------------------------------------------------------------------------------------------------ BN / pool / FPN
+@pytest.mark.parametrize("shape,relu,res", [((5, 64, 40, 50), True, False), ((5, 128, 20, 25), False, True),
+                                            ((2, 512, 5, 7), True, True), ((3, 256, 9, 11), False, False)])
+def test_batchnorm_train_fwd_bwd(ops, shape, relu, res):
+    torch.manual_seed(shape[1])
+    N, C, H, W = shape
+    x = (torch.randn(shape, dtype=torch.float64) * 2 + 0.5).requires_grad_(True)
+    r = torch.randn(shape, dtype=torch.float64, requires_grad=True) if res else None
+    g = (torch.rand(C, dtype=torch.float64) + 0.5).requires_grad_(True)
+    b = torch.randn(C, dtype=torch.float64, requires_grad=True)
+    rm, rv = torch.randn(C, dtype=torch.float64) * 0.1, torch.rand(C, dtype=torch.float64) + 0.5
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    y = F.batch_norm(x, rm_ref, rv_ref, g, b, True, 0.1, 1e-5)
+    if res:
+        y = y + r
+    if relu:
+        y = F.relu(y)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    rmd, rvd = dev(rm.float()), dev(rv.float())
+    xd = nhwc(x.detach().float())
+    rd = nhwc(r.detach().float()) if res else None
+    yd, sm, si = ops.bn_fwd(xd, dev(g.detach().float()), dev(b.detach().float()), rmd, rvd, True, 1e-5, 0.1, rd, relu)
+    close(yd, y.permute(0, 2, 3, 1), 1e-5)
+    close(rmd, rm_ref, 1e-5); close(rvd, rv_ref, 1e-5)
+    dres = torch.zeros_like(xd) if res else None
+    dx, dg, db = ops.bn_bwd(nhwc(gy.float()), xd, yd, sm, si, dev(g.detach().float()), relu, dres)
+    close(dx, x.grad.permute(0, 2, 3, 1), 2e-5)
+    close(dg, g.grad, 2e-5); close(db, b.grad, 2e-5)
+    if res:
+        close(dres, r.grad.permute(0, 2, 3, 1), 1e-6)
+
+
+def test_batchnorm_eval(ops):
+    x = torch.randn(2, 64, 8, 10, dtype=torch.float64)
+    g, b = torch.rand(64, dtype=torch.float64) + 0.5, torch.randn(64, dtype=torch.float64)
+    rm, rv = torch.randn(64, dtype=torch.float64) * 0.1, torch.rand(64, dtype=torch.float64) + 0.5
+    ref = F.relu(F.batch_norm(x, rm, rv, g, b, False, 0.1, 1e-5))
+    y, _, _ = ops.bn_fwd(nhwc(x.float()), dev(g.float()), dev(b.float()), dev(rm.float()), dev(rv.float()), False, 1e-5, 0.1, None, True)
+    close(y, ref.permute(0, 2, 3, 1), 1e-5)
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 16, 20), (1, 64, 17, 23), (5, 64, 32, 80)])
+def test_maxpool_fwd_bwd(ops, shape):
+    torch.manual_seed(3)
+    x = torch.relu(torch.randn(shape, dtype=torch.float64)).requires_grad_(True)     # zeros -> ties, like after ReLU
+    y = F.max_pool2d(x, 3, 2, 1)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    yd, arg = ops.maxpool_fwd(nhwc(x.detach().float()))
+    close(yd, y.permute(0, 2, 3, 1), 1e-7)
+    dx = ops.maxpool_bwd(nhwc(gy.float()), arg, tuple(nhwc(x.detach().float()).shape))
+    close(dx, x.grad.permute(0, 2, 3, 1), 1e-6)
+
+
+@pytest.mark.parametrize("H,W,h,w", [(40, 100, 20, 50), (8, 20, 4, 10), (9, 21, 4, 10)])
+def test_upsample_add_fwd_bwd(ops, H, W, h, w):
+    fine = torch.randn(2, 64, H, W, dtype=torch.float64, requires_grad=True)
+    coarse = torch.randn(2, 64, h, w, dtype=torch.float64, requires_grad=True)
+    ref = fine + F.interpolate(coarse, size=(H, W), mode="nearest")
+    g = torch.randn_like(ref)
+    ref.backward(g)
+    out = ops.upsample_add_(nhwc(fine.detach().float()), nhwc(coarse.detach().float()))
+    close(out, ref.permute(0, 2, 3, 1), 1e-6)
+    dc = ops.upsample_add_bwd_(nhwc(g.float()), torch.zeros(2, h, w, 64, device="cuda"))
+    close(dc, coarse.grad.permute(0, 2, 3, 1), 1e-6)
