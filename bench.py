@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""Headline benchmark: clips/s of the per-clip training step (forward + backward + AdamW) of the HIP-backed PHNet
+model on synthetic 5-frame 3x320x800 clips, ResNet-34 + router + lane head (BASELINE.json configs[1]), one clip per
+GPU per step (data parallel, weak scaling).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     - the dominant GEMM kernel's achieved TFLOP/s (algorithmic FLOPs / HIP-event time of its launches in the
+                 timed region) against the dense f32-input MFMA peak;
+  cpu_baseline - the CPU oracle (oracle/phnet_cpu.py, a restatement of the reference's PyTorch-CPU path) timed on this
+                 box's host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+F32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--arch", default="resnet34")
+    ap.add_argument("--frames", type=int, default=5)
+    ap.add_argument("--height", type=int, default=320)
+    ap.add_argument("--width", type=int, default=800)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-clips", type=int, default=2)
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(args):
+    """Times the CPU oracle's fwd+bwd on `cpu_clips` clips of the same workload (rank 0, N=1 only)."""
+    from oracle import phnet_cpu as O
+    from tests import synth
+    g = O.Geometry(img_h=args.height, img_w=args.width, arch=args.arch)
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    cores = min(cores, 16)                       # the GPU box gives one GPU a 16-core share; more threads only thrash
+    torch.set_num_threads(cores)
+    print(f"[bench] cpu baseline: {args.cpu_clips} clip(s) on {cores} threads ...", file=sys.stderr, flush=True)
+    sd = synth.make_state(g)
+    for k, v in sd.items():
+        if v.is_floating_point() and "running" not in k and k.split(".")[-1] not in ("prior_feat_ys", "prior_ys", "priors", "priors_on_featmap"):
+            v.requires_grad_(True)
+    frames, lanes = synth.make_clip(g, args.frames), synth.make_targets(g, args.frames)
+    t0 = time.perf_counter()
+    for i in range(args.cpu_clips):
+        loss = O.clip_forward(sd, frames, lanes, g, training=True)
+        loss.backward()
+        print(f"[bench] cpu baseline clip {i + 1}/{args.cpu_clips} done at {time.perf_counter() - t0:.1f} s", file=sys.stderr, flush=True)
+    dt = time.perf_counter() - t0
+    return {"value": args.cpu_clips / dt, "unit": "clips/s", "cores": cores, "kind": "port",
+            "sample": f"{args.cpu_clips} clips of {args.frames}x3x{args.height}x{args.width} fwd+bwd (no optimizer, no warm-up), "
+                      f"oracle/phnet_cpu.py on torch CPU fp32, {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", init_method="env://")
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    from phnet_amd import hip_ops
+    from phnet_amd.config import make_cfg
+    from phnet_amd.libs.models.Router4OL import RouterOL
+    from phnet_amd.libs.utils.loss4OLV3 import Criterion4OL
+    from phnet_amd.synthetic import make_clip, make_targets
+
+    torch.manual_seed(3407)
+    cfg = make_cfg(img_h=args.height, img_w=args.width, arch=args.arch)
+    model = RouterOL(cfg, Criterion4OL(cfg)).to(dev).train()
+    # random-init cls/reg heads (std 1e-3) give ~0.5 scores everywhere, like the reference at initialisation
+    net = model
+    if world > 1:
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], broadcast_buffers=False)
+    decay = [p for p in model.parameters() if p.dim() > 1]
+    no_decay = [p for p in model.parameters() if p.dim() <= 1]
+    opt = torch.optim.AdamW([{"params": decay, "weight_decay": 5e-4}, {"params": no_decay, "weight_decay": 0.0}],
+                            lr=5e-4, betas=(0.9, 0.999), fused=True)
+    T = args.frames
+    lanes = make_targets(args.height, args.width, T).to(dev)
+    clips = [make_clip(args.height, args.width, T, seed=3407 + rank + 17 * i).to(dev) for i in range(4)]
+
+    def step(i):
+        opt.zero_grad(set_to_none=True)
+        loss = net({"frame": clips[i % len(clips)], "lanes": lanes}) / T
+        loss.backward()
+        opt.step()
+        return loss
+
+    for i in range(args.warmup):
+        step(i)
+        torch.cuda.synchronize()
+        print(f"[bench] rank {rank} warm-up step {i + 1}/{args.warmup} done", file=sys.stderr, flush=True)
+    if world > 1:
+        dist.barrier()
+    timer_on = not args.no_kernel_timer
+    if timer_on:
+        hip_ops.TIMER = []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    records, hip_ops.TIMER = hip_ops.TIMER, None
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    print(f"[bench] rank {rank}: {args.steps} timed steps in {dt:.3f} s", file=sys.stderr, flush=True)
+
+    if rank == 0:
+        roof = None
+        if records:
+            agg = {}
+            for sym, splits, flops, e0, e1 in records:
+                if splits != 1:
+                    continue                                   # bracket would include the split-K reduce kernel
+                a = agg.setdefault(sym, [0, 0.0, 0.0])
+                a[0] += 1; a[1] += flops; a[2] += e0.elapsed_time(e1) * 1e-3
+            total_gemm_s = sum(a[2] for a in agg.values())
+            sym, (n, fl, sec) = max(agg.items(), key=lambda kv: kv[1][2])
+            ach = fl / sec / 1e12
+            roof = {"bound": "mfma", "kernel": sym, "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "launches": n, "avg_launch_us": round(sec / n * 1e6, 2), "gflop_per_launch": round(fl / n / 1e9, 3),
+                    "mfma_dtype": "f32 (v_mfma_f32_32x32x2_f32)",
+                    "all_gemm_kernels": {k: {"launches": v[0], "TFLOP/s": round(v[1] / v[2] / 1e12, 2), "ms_per_step": round(v[2] / args.steps * 1e3, 3)}
+                                         for k, v in sorted(agg.items())},
+                    "gemm_ms_per_step": round(total_gemm_s / args.steps * 1e3, 3)}
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(args)
+        out = {"metric": "clips/s (5x3x320x800) fwd+bwd", "value": round(world * args.steps / dt, 4), "unit": "clips/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"{T}-frame clip 3x{args.height}x{args.width}, {args.arch} + router + lane head, fwd+bwd+AdamW, "
+                                      f"1 clip/GPU/step, random-init weights", "parallelism": f"dp{world}",
+                          "timed_region": "zero_grad + forward + loss + backward (+DDP all-reduce) + optimizer step"},
+               "loss": round(float(loss.item()), 4), "roofline": roof, "cpu_baseline": cpu}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

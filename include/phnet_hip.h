@@ -43,7 +43,8 @@ int phnet_lane_nms(const float* rows, const float* scores, const int32_t* counts
 /* ---- lane-anchor ROI pooling: replaces F.grid_sample(..., align_corners=True) + permutes
  * (libs/models/Router4OL.py:132-150, 269-272) and its backward (ATen grid_sampler_2d_backward).
  * fmap [B][h][w][64]; xs [B][N][P] = priors_on_featmap (un-flipped); ys [P] = prior_feat_ys; out [B][N][P][64]. */
-int phnet_roi_pool_fwd(const float* fmap, const float* xs, const float* ys, float* out,
+/* out_cp (optional): the same samples laid out [B][N][64][P] for the routing gate. */
+int phnet_roi_pool_fwd(const float* fmap, const float* xs, const float* ys, float* out, float* out_cp,
                        int32_t B, int32_t N, int32_t P, int32_t h, int32_t w, int32_t C, void* stream);
 /* dmap [B][h][w][64] is accumulated into (may be NULL); dxs [B][N][P] is overwritten (may be NULL). */
 int phnet_roi_pool_bwd(const float* dout, const float* fmap, const float* xs, const float* ys,
@@ -57,9 +58,12 @@ int phnet_roi_pool_bwd(const float* dout, const float* fmap, const float* xs, co
 int phnet_conv2d_fwd(const float* x, const float* w, const float* bias, float* y,
                      int32_t N, int32_t Hi, int32_t Wi, int32_t Ci, int32_t Co, int32_t R, int32_t S,
                      int32_t stride, int32_t pad, int32_t relu, void* workspace, uint64_t ws_bytes, void* stream);
-int phnet_conv2d_dgrad(const float* dy, const float* w, float* dx,
+/* dx = dgrad(dy, w) (+ addend): addend is optional, shaped like dx, and may alias dx. */
+int phnet_conv2d_dgrad(const float* dy, const float* w, const float* addend, float* dx,
                        int32_t N, int32_t Hi, int32_t Wi, int32_t Ci, int32_t Co, int32_t R, int32_t S,
                        int32_t stride, int32_t pad, void* workspace, uint64_t ws_bytes, void* stream);
+/* host-side query (no device work; bm/bn/splits are HOST pointers): tile and split-K factor the two calls above use. */
+int phnet_conv2d_plan(int64_t M, int32_t Co, int32_t K, uint64_t ws_bytes, int32_t* bm, int32_t* bn, int32_t* splits);
 uint64_t phnet_conv2d_wgrad_workspace(int32_t N, int32_t Hi, int32_t Wi, int32_t Ci, int32_t Co,
                                       int32_t R, int32_t S, int32_t stride, int32_t pad);
 int phnet_conv2d_wgrad(const float* dy, const float* x, float* dw,
@@ -89,6 +93,26 @@ int phnet_maxpool3x3s2_bwd(const float* dy, const uint8_t* argmax, float* dx, in
 /* ---- FPN top-down add: laterals[i-1] += F.interpolate(laterals[i], size=..., mode='nearest') (libs/models/fpn.py:127-141) ---- */
 int phnet_upsample_add(float* fine, const float* coarse, int32_t N, int32_t H, int32_t W, int32_t h, int32_t w, int32_t C, void* stream);
 int phnet_upsample_add_bwd(const float* dfine, float* dcoarse, int32_t N, int32_t H, int32_t W, int32_t h, int32_t w, int32_t C, void* stream);
+
+/* ---- LayerNorm (+residual)(+ReLU): replaces F.layer_norm at Router.py:72-81, utils/dynamic_head.py:42-58,
+ * utils/transformer.py:275-298.  rows x L, affine w/b [L]; y = relu?(LN(x)*w + b (+res)). ---- */
+int phnet_layernorm_fwd(const float* x, const float* w, const float* b, const float* res, float* y,
+                        float* mean, float* rstd, int64_t rows, int32_t L, float eps, int32_t relu, void* stream);
+uint64_t phnet_layernorm_bwd_workspace(int64_t rows, int32_t L);
+int phnet_layernorm_bwd(const float* dy, const float* x, const float* y, const float* w,
+                        const float* mean, const float* rstd, float* dx, float* dres, float* dw, float* db,
+                        int64_t rows, int32_t L, int32_t relu, int32_t param_accumulate,
+                        void* workspace, uint64_t ws_bytes, void* stream);
+
+/* ---- routing-gate depth-wise 3x3: replaces Conv2d(N,N,3,padding=1,groups=N) (libs/models/Router.py:55-61).
+ * x,y [N][C][P] planes (one per anchor), w [N][3][3], bias [N] or NULL; flip=1 computes the data gradient. ---- */
+int phnet_dwconv3x3(const float* x, const float* w, const float* bias, float* y,
+                    int32_t N, int32_t C, int32_t P, int32_t flip, void* stream);
+int phnet_dwconv3x3_wgrad(const float* dy, const float* x, float* dw, float* db,
+                          int32_t N, int32_t C, int32_t P, int32_t accumulate, void* stream);
+
+/* ---- ReLU backward through the saved output (fused-ReLU epilogues of the linears) ---- */
+int phnet_relu_bwd(const float* dy, const float* y, float* dx, int64_t n, void* stream);
 
 /* ---- bias gradients: column sums of [M][C] ---- */
 uint64_t phnet_colsum_workspace(int64_t M, int32_t C);

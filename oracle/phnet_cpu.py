@@ -282,6 +282,8 @@ class FrameOutput:
     predictions_sec: List[Tensor]
     attn_feats: List[Tensor]          # per stage [N,128]: this frame's memory source
     gates: List[Tensor]               # per stage [1,N,1]
+    stage_inputs: List[dict] = field(default_factory=list)   # per stage: priors/on_map/pro/mem fed to that stage (tests)
+    locals_: List[Tensor] = field(default_factory=list)      # per stage dynamic-head output [1,N,C]
 
 
 def lane_head_frame(sd: State, feats: Sequence[Tensor], memory: List[List[Tensor]], g: Geometry,
@@ -298,10 +300,13 @@ def lane_head_frame(sd: State, feats: Sequence[Tensor], memory: List[List[Tensor
     out = FrameOutput([], [], [], [])
     sxi = sample_x_indexs(g)
     for stage in range(g.refine_layers):
+        out.stage_inputs.append(dict(priors=priors.detach(), on_map=on_map.detach(), pro=pro.detach(),
+                                     mem=[fr[stage] for fr in memory]))
         pooled = pool_anchor_features(levels[stage], on_map, g)                 # [1,N,C,P]
         gate = routing_gate(sd, stage, pooled.detach(), prefix + "router.")
         local = dynamic_head(sd, stage, pro, pooled.transpose(2, 3), prefix + "DHead_series.")
         pro = local.detach()
+        out.locals_.append(local.detach())
         pred_a, lines_a = branch_heads(sd, local, priors, g, "", prefix)
         attn = torch.cat([local[0], pos], dim=-1)                               # [N,128]
         mem = [fr[stage] for fr in memory]

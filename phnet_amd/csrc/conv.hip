@@ -37,7 +37,7 @@ struct RowCoord { int base, iy0, ix0; bool ok; };
 template <int BM, int BN, bool B_DGRAD>
 __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(
     const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ bias,
-    float* __restrict__ out, ConvShape g, int relu)
+    const float* __restrict__ addend, float* __restrict__ out, ConvShape g, int relu)
 {
     constexpr int TM = BM / 2, TN = BN / 2, FM = TM / 32, FN = TN / 32;
     constexpr int A_FLOATS = KContigTile<BM>::FLOATS;
@@ -182,6 +182,7 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(
                 const int m = m0 + wm + i * 32 + frag_row(lane, e);
                 if (m < M) {
                     float v = acc[i][j][e] + bv;
+                    if (final_pass && addend) v += addend[(size_t)m * g.Co + n];
                     if (final_pass && relu) v = fmaxf(v, 0.f);
                     dst[(size_t)m * g.Co + n] = v;
                 }
@@ -191,8 +192,8 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(
 
 // out[i] = sum_z part[z][i] (+bias[i % ncols]) (relu)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ out,
-                                                            const float* __restrict__ bias, long total4, int ncols,
-                                                            int splits, int relu, int accumulate)
+                                                            const float* __restrict__ bias, const float* __restrict__ addend,
+                                                            long total4, int ncols, int splits, int relu, int accumulate)
 {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total4) return;
@@ -202,6 +203,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         const int c = (int)((i * 4) % ncols);
         s += *reinterpret_cast<const f32x4*>(bias + c);
     }
+    if (addend) s += reinterpret_cast<const f32x4*>(addend)[i];
     if (relu) { s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f); }
     if (accumulate) s += reinterpret_cast<const f32x4*>(out)[i];
     reinterpret_cast<f32x4*>(out)[i] = s;
@@ -361,28 +363,38 @@ TileChoice pick_tile(long M, long N)
     return {64, 64};
 }
 
+struct ConvPlan { int bm, bn, splits; long tiles; };
+
+ConvPlan plan_conv(long M, int Co, int K, bool has_ws, size_t ws_bytes)
+{
+    const TileChoice t = pick_tile(M, Co);
+    ConvPlan p{t.bm, t.bn, 1, ceil_div64(M, t.bm) * ceil_div64(Co, t.bn)};
+    // split K when the tile grid cannot fill the chip and K is long enough to amortise the reduce
+    if (has_ws && p.tiles < 256) {
+        int splits = (int)min((long)16, max((long)1, 512 / p.tiles));
+        while (splits > 1 && K / splits < 256) --splits;
+        while (splits > 1 && (size_t)splits * M * Co * sizeof(float) > ws_bytes) --splits;
+        p.splits = splits;
+    }
+    return p;
+}
+
 template <bool DGRAD>
-int launch_conv(const float* X, const float* W, const float* bias, float* out, float* workspace, size_t ws_bytes,
-                ConvShape g, int relu, hipStream_t st)
+int launch_conv(const float* X, const float* W, const float* bias, const float* addend, float* out, float* workspace,
+                size_t ws_bytes, ConvShape g, int relu, hipStream_t st)
 {
     const long M = (long)g.N * g.Ho * g.Wo;
     const int K = g.R * g.S * g.Ci;
-    const TileChoice t = pick_tile(M, g.Co);
-    const long tiles = ceil_div64(M, t.bm) * ceil_div64(g.Co, t.bn);
-    // split K when the tile grid cannot fill the chip and K is long enough to amortise the reduce
-    int splits = 1;
-    if (workspace && tiles < 256) {
-        splits = (int)min((long)16, max((long)1, 512 / tiles));
-        while (splits > 1 && K / splits < 256) --splits;
-        while (splits > 1 && (size_t)splits * M * g.Co * sizeof(float) > ws_bytes) --splits;
-    }
+    const ConvPlan t = plan_conv(M, g.Co, K, workspace != nullptr, ws_bytes);
+    const long tiles = t.tiles;
+    const int splits = t.splits;
     const int ksteps = (K + BK - 1) / BK;
     g.splits = splits;
     g.k_per_split = ((ksteps + splits - 1) / splits) * BK;
     float* dst = splits > 1 ? workspace : out;
     dim3 grid((unsigned)tiles, 1, (unsigned)splits);
 #define PHNET_LAUNCH_CONV(BM_, BN_) \
-    hipLaunchKernelGGL((conv_igemm_kernel<BM_, BN_, DGRAD>), grid, dim3(THREADS), 0, st, X, W, bias, dst, g, relu)
+    hipLaunchKernelGGL((conv_igemm_kernel<BM_, BN_, DGRAD>), grid, dim3(THREADS), 0, st, X, W, bias, addend, dst, g, relu)
     if (t.bm == 128 && t.bn == 128) PHNET_LAUNCH_CONV(128, 128);
     else if (t.bm == 128 && t.bn == 64) PHNET_LAUNCH_CONV(128, 64);
     else if (t.bm == 64 && t.bn == 128) PHNET_LAUNCH_CONV(64, 128);
@@ -391,12 +403,22 @@ int launch_conv(const float* X, const float* W, const float* bias, float* out, f
     if (splits > 1) {
         const long total4 = M * g.Co / 4;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)ceil_div64(total4, 256)), dim3(256), 0, st,
-                           workspace, out, bias, total4, g.Co, splits, relu, 0);
+                           workspace, out, bias, addend, total4, g.Co, splits, relu, 0);
     }
     return phnet_launch_status();
 }
 
 }  // namespace
+
+// Which kernel instantiation / split-K factor phnet_conv2d_fwd / _dgrad will use for a GEMM of M x Co x K
+// (profiling aid for bench.py: lets the host attribute event timings to one kernel symbol).
+PHNET_API int phnet_conv2d_plan(int64_t M, int32_t Co, int32_t K, uint64_t ws_bytes, int32_t* bm, int32_t* bn, int32_t* splits)
+{
+    if (M < 1 || Co < 1 || K < 1 || !bm || !bn || !splits) return PHNET_ERR_ARG;
+    const ConvPlan p = plan_conv((long)M, Co, K, ws_bytes > 0, (size_t)ws_bytes);
+    *bm = p.bm; *bn = p.bn; *splits = p.splits;
+    return PHNET_OK;
+}
 
 // Forward convolution / linear.  x NHWC [N][Hi][Wi][Ci], w OHWI [Co][R][S][Ci], bias [Co] or NULL,
 // y NHWC [N][Ho][Wo][Co].  Ci % 4 == 0, Co % 4 == 0.  workspace (optional, for split-K) is caller-allocated.
@@ -415,11 +437,12 @@ PHNET_API int phnet_conv2d_fwd(const float* x, const float* w, const float* bias
     g.Wo = (Wi + 2 * pad - S) / stride + 1;
     if (g.Ho < 1 || g.Wo < 1) return PHNET_ERR_ARG;
     g.stride = stride; g.pad = pad; g.in_dil = 1;
-    return launch_conv<false>(x, w, bias, y, (float*)workspace, ws_bytes, g, relu, (hipStream_t)stream);
+    return launch_conv<false>(x, w, bias, nullptr, y, (float*)workspace, ws_bytes, g, relu, (hipStream_t)stream);
 }
 
 // Data gradient.  dy NHWC [N][Ho][Wo][Co], w OHWI [Co][R][S][Ci] (as used by the forward), dx NHWC [N][Hi][Wi][Ci].
-PHNET_API int phnet_conv2d_dgrad(const float* dy, const float* w, float* dx,
+// addend (optional, same shape as dx, may alias dx): dx = dgrad + addend  (residual-branch gradient).
+PHNET_API int phnet_conv2d_dgrad(const float* dy, const float* w, const float* addend, float* dx,
                                  int32_t N, int32_t Hi, int32_t Wi, int32_t Ci, int32_t Co, int32_t R, int32_t S,
                                  int32_t stride, int32_t pad, void* workspace, uint64_t ws_bytes, void* stream)
 {
@@ -437,7 +460,7 @@ PHNET_API int phnet_conv2d_dgrad(const float* dy, const float* w, float* dx,
     g.stride = 1; g.pad = R - 1 - pad; g.in_dil = stride;
     if (R != S && (S - 1 - pad) != g.pad) return PHNET_ERR_ARG;   // square padding only
     if (g.pad < 0) return PHNET_ERR_ARG;
-    return launch_conv<true>(dy, w, nullptr, dx, (float*)workspace, ws_bytes, g, 0, (hipStream_t)stream);
+    return launch_conv<true>(dy, w, nullptr, addend, dx, (float*)workspace, ws_bytes, g, 0, (hipStream_t)stream);
 }
 
 // Weight gradient.  dw OHWI [Co][R][S][Ci] is overwritten (accumulate=0) or added to (accumulate=1).
@@ -488,7 +511,8 @@ PHNET_API int phnet_conv2d_wgrad(const float* dy, const float* x, float* dw,
     else hipLaunchKernelGGL((conv_wgrad_kernel<64, 64>), grid, dim3(THREADS), 0, st, dy, x, (float*)workspace, g);
     const long total4 = (long)Co * NC / 4;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)ceil_div64(total4, 256)), dim3(256), 0, st,
-                       (const float*)workspace, dw, (const float*)nullptr, total4, (int)NC, (int)splits, 0, accumulate);
+                       (const float*)workspace, dw, (const float*)nullptr, (const float*)nullptr, total4, (int)NC, (int)splits, 0,
+                       accumulate);
     return phnet_launch_status();
 }
 

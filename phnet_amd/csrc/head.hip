@@ -1,0 +1,258 @@
+// Lane-head normalisation / gate kernels for gfx950: LayerNorm (+residual)(+ReLU) forward/backward and the
+// per-anchor depth-wise 3x3 convolution of the adaptive routing gate, forward/backward.
+//
+// Replaces the ATen ops behind
+//   libs/models/Router.py:72-81      (LayerNorm([C,P]) -> 4 x relu(DWblock(x)+x); Conv2d(N,N,3,padding=1,groups=N))
+//   libs/models/utils/dynamic_head.py:42-58  (norm1/norm2 + ReLU, norm3)
+//   libs/models/utils/transformer.py:275-298 (pre-norm LayerNorms)
+// All HBM/LDS-bound: one wavefront per LayerNorm row (wave shuffles for the two reductions), one workgroup
+// per anchor plane for the depth-wise filter (plane staged in LDS once, 9 taps from LDS).
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+// ---- LayerNorm over the last L elements: y = relu?( (x-mu)*rstd*w + b (+res) ) ---------------------------
+__global__ __launch_bounds__(NT) void layernorm_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ res,
+    float* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd, long rows, int L, float eps, int relu)
+{
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * L;
+    float s = 0.f;
+    for (int i = lane; i < L; i += 64) s += xr[i];
+    const float mu = wave_sum(s) / (float)L;
+    float v = 0.f;
+    for (int i = lane; i < L; i += 64) { const float d = xr[i] - mu; v += d * d; }
+    const float rs = 1.0f / sqrtf(wave_sum(v) / (float)L + eps);
+    if (lane == 0 && mean) { mean[row] = mu; rstd[row] = rs; }
+    float* yr = y + (size_t)row * L;
+    const float* rr = res ? res + (size_t)row * L : nullptr;
+    for (int i = lane; i < L; i += 64) {
+        float o = (xr[i] - mu) * rs * w[i] + b[i];
+        if (rr) o += rr[i];
+        if (relu) o = fmaxf(o, 0.f);
+        yr[i] = o;
+    }
+}
+
+// g = dy * (y>0 if relu); dx = rstd*(g*w - mean(g*w) - xhat*mean(g*w*xhat)); dres = g
+__global__ __launch_bounds__(NT) void layernorm_bwd_dx_kernel(
+    const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ w,
+    const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ dx, float* __restrict__ dres,
+    long rows, int L, int relu)
+{
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const size_t o = (size_t)row * L;
+    const float mu = mean[row], rs = rstd[row];
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = lane; i < L; i += 64) {
+        float g = dy[o + i];
+        if (relu && !(y[o + i] > 0.f)) g = 0.f;
+        const float gw = g * w[i];
+        s1 += gw;
+        s2 += gw * ((x[o + i] - mu) * rs);
+    }
+    s1 = wave_sum(s1) / (float)L;
+    s2 = wave_sum(s2) / (float)L;
+    for (int i = lane; i < L; i += 64) {
+        float g = dy[o + i];
+        if (relu && !(y[o + i] > 0.f)) g = 0.f;
+        const float xh = (x[o + i] - mu) * rs;
+        dx[o + i] = rs * (g * w[i] - s1 - xh * s2);
+        if (dres) dres[o + i] = g;
+    }
+}
+
+// partial[slab][0][L] = sum_rows g*xhat, partial[slab][1][L] = sum_rows g   (rows of this slab)
+__global__ __launch_bounds__(NT) void layernorm_bwd_param_partial_kernel(
+    const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y,
+    const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ partial,
+    long rows, int L, long rows_per_slab, int relu)
+{
+    __shared__ float r0[NT], r1[NT];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rl = threadIdx.x >> 6;
+    const long a = (long)blockIdx.y * rows_per_slab, e = min(rows, a + rows_per_slab);
+    float sw = 0.f, sb = 0.f;
+    if (col < L)
+        for (long r = a + rl; r < e; r += NT / 64) {
+            const size_t o = (size_t)r * L + col;
+            float g = dy[o];
+            if (relu && !(y[o] > 0.f)) g = 0.f;
+            sw += g * ((x[o] - mean[r]) * rstd[r]);
+            sb += g;
+        }
+    r0[threadIdx.x] = sw; r1[threadIdx.x] = sb;
+    __syncthreads();
+    if (rl == 0 && col < L) {
+        const int t = threadIdx.x;
+        partial[((size_t)blockIdx.y * 2 + 0) * L + col] = (r0[t] + r0[t + 64]) + (r0[t + 128] + r0[t + 192]);
+        partial[((size_t)blockIdx.y * 2 + 1) * L + col] = (r1[t] + r1[t + 64]) + (r1[t + 128] + r1[t + 192]);
+    }
+}
+
+__global__ void layernorm_bwd_param_finalize_kernel(const float* __restrict__ partial, float* __restrict__ dw,
+                                                    float* __restrict__ db, int slabs, int L, int accumulate)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= L) return;
+    double sw = 0.0, sb = 0.0;
+    for (int s = 0; s < slabs; ++s) {
+        sw += (double)partial[((size_t)s * 2 + 0) * L + c];
+        sb += (double)partial[((size_t)s * 2 + 1) * L + c];
+    }
+    dw[c] = accumulate ? dw[c] + (float)sw : (float)sw;
+    db[c] = accumulate ? db[c] + (float)sb : (float)sb;
+}
+
+// ---- depth-wise 3x3 over each anchor's (C x P) plane, zero padding 1 --------------------------------------
+// plane layout [C][P]: element (c, p) at c*P + p (the reference's [1,N,C,P]; the ROI pooling kernel emits this
+// copy for the gate); filter w[n][i][j] with i along c and j along p (PyTorch's [N,1,3,3]), bias[n].
+// flip=1 correlates with the 180-degree rotated filter (data gradient).
+__global__ __launch_bounds__(NT) void dwconv3x3_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, float* __restrict__ y,
+                                                       int C, int P, int flip)
+{
+    extern __shared__ float plane[];
+    const int n = blockIdx.x;
+    const int CP = C * P;
+    const float* xp = x + (size_t)n * CP;
+    for (int i = threadIdx.x; i < CP; i += NT) plane[i] = xp[i];
+    float f[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) f[k] = w[n * 9 + (flip ? 8 - k : k)];
+    const float bv = bias ? bias[n] : 0.f;
+    __syncthreads();
+    for (int i = threadIdx.x; i < CP; i += NT) {
+        const int c = i / P, p = i - c * P;
+        float acc = bv;
+#pragma unroll
+        for (int di = 0; di < 3; ++di) {
+            const int cc = c + di - 1;
+            if (cc < 0 || cc >= C) continue;
+#pragma unroll
+            for (int dj = 0; dj < 3; ++dj) {
+                const int pp = p + dj - 1;
+                if (pp < 0 || pp >= P) continue;
+                acc += f[di * 3 + dj] * plane[cc * P + pp];
+            }
+        }
+        y[(size_t)n * CP + i] = acc;
+    }
+}
+
+// dw[n][i][j] = sum_{c,p} dy(c,p) * x(c+i-1, p+j-1);  db[n] = sum dy
+__global__ __launch_bounds__(NT) void dwconv3x3_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                             float* __restrict__ dw, float* __restrict__ db,
+                                                             int C, int P, int accumulate)
+{
+    extern __shared__ float plane[];
+    __shared__ float red[10][NT / 64];
+    const int n = blockIdx.x;
+    const int CP = C * P;
+    for (int i = threadIdx.x; i < CP; i += NT) plane[i] = x[(size_t)n * CP + i];
+    __syncthreads();
+    float acc[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) acc[k] = 0.f;
+    for (int i = threadIdx.x; i < CP; i += NT) {
+        const int c = i / P, p = i - c * P;
+        const float g = dy[(size_t)n * CP + i];
+        acc[9] += g;
+#pragma unroll
+        for (int di = 0; di < 3; ++di) {
+            const int cc = c + di - 1;
+            if (cc < 0 || cc >= C) continue;
+#pragma unroll
+            for (int dj = 0; dj < 3; ++dj) {
+                const int pp = p + dj - 1;
+                if (pp < 0 || pp >= P) continue;
+                acc[di * 3 + dj] += g * plane[cc * P + pp];
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+        const float v = wave_sum(acc[k]);
+        if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 10) {
+        const float v = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+        float* dst = threadIdx.x < 9 ? dw + n * 9 + threadIdx.x : db + n;
+        *dst = accumulate ? *dst + v : v;
+    }
+}
+
+}  // namespace
+
+// y[rows][L] = relu?( LayerNorm(x) * w + b (+ res) ); mean/rstd [rows] saved for the backward (may be NULL).
+PHNET_API int phnet_layernorm_fwd(const float* x, const float* w, const float* b, const float* res, float* y,
+                                  float* mean, float* rstd, int64_t rows, int32_t L, float eps, int32_t relu, void* stream)
+{
+    if (rows < 0 || L < 1) return PHNET_ERR_ARG;
+    if (rows == 0) return PHNET_OK;
+    if (!x || !w || !b || !y || (!!mean != !!rstd)) return PHNET_ERR_ARG;
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((unsigned)ceil_div64(rows, NT / 64)), dim3(NT), 0, (hipStream_t)stream,
+                       x, w, b, res, y, mean, rstd, (long)rows, L, eps, relu);
+    return phnet_launch_status();
+}
+
+PHNET_API uint64_t phnet_layernorm_bwd_workspace(int64_t rows, int32_t L)
+{
+    const long slabs = max((long)1, min((long)128, (long)rows / 32));
+    return (uint64_t)(slabs * 2 * L * sizeof(float));
+}
+
+// dy: gradient of the output (after the optional ReLU whose mask is y > 0).  dx overwritten; dres (optional)
+// overwritten with the masked gradient (residual branch); dw/db [L] overwritten or accumulated.
+PHNET_API int phnet_layernorm_bwd(const float* dy, const float* x, const float* y, const float* w,
+                                  const float* mean, const float* rstd, float* dx, float* dres, float* dw, float* db,
+                                  int64_t rows, int32_t L, int32_t relu, int32_t param_accumulate,
+                                  void* workspace, uint64_t ws_bytes, void* stream)
+{
+    if (rows < 0 || L < 1) return PHNET_ERR_ARG;
+    if (rows == 0) return PHNET_OK;
+    if (!dy || !x || !w || !mean || !rstd || !dx || (relu && !y)) return PHNET_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(layernorm_bwd_dx_kernel, dim3((unsigned)ceil_div64(rows, NT / 64)), dim3(NT), 0, st,
+                       dy, x, y, w, mean, rstd, dx, dres, (long)rows, L, relu);
+    if (dw && db) {
+        const long slabs = max((long)1, min((long)128, (long)rows / 32));
+        if (!workspace || (uint64_t)(slabs * 2 * L * sizeof(float)) > ws_bytes) return PHNET_ERR_WORKSPACE;
+        const long rps = ceil_div64(rows, slabs);
+        hipLaunchKernelGGL(layernorm_bwd_param_partial_kernel, dim3((L + 63) / 64, (unsigned)slabs), dim3(NT), 0, st,
+                           dy, x, y, mean, rstd, (float*)workspace, (long)rows, L, rps, relu);
+        hipLaunchKernelGGL(layernorm_bwd_param_finalize_kernel, dim3((L + 255) / 256), dim3(256), 0, st,
+                           (const float*)workspace, dw, db, (int)slabs, L, param_accumulate);
+    }
+    return phnet_launch_status();
+}
+
+// x,y [N][C][P] planes; w [N][3][3] (i along C, j along P); bias [N] or NULL; flip=1 -> data gradient.
+PHNET_API int phnet_dwconv3x3(const float* x, const float* w, const float* bias, float* y,
+                              int32_t N, int32_t C, int32_t P, int32_t flip, void* stream)
+{
+    if (N < 0 || C < 1 || P < 1 || (size_t)C * P * 4 > 64 * 1024) return PHNET_ERR_ARG;
+    if (N == 0) return PHNET_OK;
+    if (!x || !w || !y) return PHNET_ERR_ARG;
+    hipLaunchKernelGGL(dwconv3x3_kernel, dim3(N), dim3(NT), (size_t)C * P * 4, (hipStream_t)stream, x, w, bias, y, C, P, flip);
+    return phnet_launch_status();
+}
+
+PHNET_API int phnet_dwconv3x3_wgrad(const float* dy, const float* x, float* dw, float* db,
+                                    int32_t N, int32_t C, int32_t P, int32_t accumulate, void* stream)
+{
+    if (N < 0 || C < 1 || P < 1 || (size_t)C * P * 4 > 60 * 1024) return PHNET_ERR_ARG;
+    if (N == 0) return PHNET_OK;
+    if (!dy || !x || !dw || !db) return PHNET_ERR_ARG;
+    hipLaunchKernelGGL(dwconv3x3_wgrad_kernel, dim3(N), dim3(NT), (size_t)C * P * 4, (hipStream_t)stream, dy, x, dw, db, C, P,
+                       accumulate);
+    return phnet_launch_status();
+}

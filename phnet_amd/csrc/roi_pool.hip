@@ -40,7 +40,7 @@ __device__ __forceinline__ Corners corners_of(float xn, float yn, int h, int w) 
 
 __global__ __launch_bounds__(ROI_THREADS) void roi_pool_fwd_kernel(
     const float* __restrict__ fmap, const float* __restrict__ xs, const float* __restrict__ ys,
-    float* __restrict__ out, int B, int N, int P, int h, int w)
+    float* __restrict__ out, float* __restrict__ out_cp, int B, int N, int P, int h, int w)
 {
     const int lane = threadIdx.x & 63;
     const long sample = (long)blockIdx.x * (ROI_THREADS / 64) + (threadIdx.x >> 6);
@@ -71,6 +71,7 @@ __global__ __launch_bounds__(ROI_THREADS) void roi_pool_fwd_kernel(
         acc = xn * 0.0f;        // NaN in -> NaN out, like ATen
     }
     out[sample * ROI_C + lane] = acc;
+    if (out_cp) out_cp[(bn * ROI_C + lane) * P + k] = acc;       // [B][N][C][P] copy for the routing gate
 }
 
 __global__ __launch_bounds__(ROI_THREADS) void roi_pool_bwd_kernel(
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(ROI_THREADS) void roi_pool_bwd_kernel(
         const bool x0in = c.x0 >= 0 && c.x0 < w, x1in = c.x0 + 1 >= 0 && c.x0 + 1 < w;
         const bool y0in = c.y0 >= 0 && c.y0 < h, y1in = c.y0 + 1 >= 0 && c.y0 + 1 < h;
         const float fx = floorf(c.ix), fy = floorf(c.iy);
-        const float xe = fx + 1.0f, ye = fy + 1.0f;
+        const float ye = fy + 1.0f;
         if (y0in && x0in) {
             const size_t o = plane + ((size_t)c.y0 * w + c.x0) * ROI_C;
             if (dmap) atomicAdd(dmap + o, g * c.nw);
@@ -128,7 +129,8 @@ __global__ __launch_bounds__(ROI_THREADS) void roi_pool_bwd_kernel(
 
 // fmap [B][h][w][64] f32 NHWC; xs [B][N][P] normalised anchor x per sample row (un-flipped
 // priors_on_featmap); ys [P] = prior_feat_ys; out [B][N][P][64].
-PHNET_API int phnet_roi_pool_fwd(const float* fmap, const float* xs, const float* ys, float* out,
+// out_cp (optional): the same samples as [B][N][64][P] (the layout the routing gate consumes).
+PHNET_API int phnet_roi_pool_fwd(const float* fmap, const float* xs, const float* ys, float* out, float* out_cp,
                                  int32_t B, int32_t N, int32_t P, int32_t h, int32_t w, int32_t C, void* stream)
 {
     if (C != ROI_C || B < 0 || N < 0 || P < 0 || h < 1 || w < 1) return PHNET_ERR_ARG;
@@ -137,7 +139,7 @@ PHNET_API int phnet_roi_pool_fwd(const float* fmap, const float* xs, const float
     if (!fmap || !xs || !ys || !out) return PHNET_ERR_ARG;
     const unsigned blocks = (unsigned)ceil_div64(total, ROI_THREADS / 64);
     hipLaunchKernelGGL(roi_pool_fwd_kernel, dim3(blocks), dim3(ROI_THREADS), 0, (hipStream_t)stream,
-                       fmap, xs, ys, out, B, N, P, h, w);
+                       fmap, xs, ys, out, out_cp, B, N, P, h, w);
     return phnet_launch_status();
 }
 

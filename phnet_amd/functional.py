@@ -1,0 +1,137 @@
+"""Autograd nodes of the lane head, each one a thin shell around C-ABI kernels (phnet_amd/hip_ops.py).
+
+Forward and backward of every node run hand-written HIP kernels; torch.autograd only orders the nodes.
+"""
+from typing import Optional
+
+import torch
+
+from . import hip_ops as K
+
+
+class _Linear(torch.autograd.Function):
+    """y = relu?(x @ w.T + b) on the fp32-MFMA GEMM (replaces F.linear / addmm).
+    Output widths that are not a multiple of 4 (the 1/2-wide score heads) are zero-padded to 4 for the kernel."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, relu):
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        n = w.shape[0]
+        npad = (-n) % 4
+        wc = w.contiguous() if npad == 0 else torch.cat([w, w.new_zeros(npad, w.shape[1])], 0)
+        bc = None if b is None else (b.contiguous() if npad == 0 else torch.cat([b, b.new_zeros(npad)], 0))
+        y = K.linear_fwd(x2, wc, bc, relu)
+        ctx.save_for_backward(x2, wc, y if relu else None)
+        ctx.relu, ctx.has_b, ctx.xshape, ctx.n = relu, b is not None, x.shape, n
+        out = y if npad == 0 else y[:, :n]
+        return out.reshape(*x.shape[:-1], n)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, y = ctx.saved_tensors
+        n, n4 = ctx.n, w.shape[0]
+        g = dy.reshape(-1, n)
+        if n4 != n:
+            g = torch.cat([g, g.new_zeros(g.shape[0], n4 - n)], 1)
+        g = g.contiguous()
+        if ctx.relu:
+            g = K.relu_bwd(g, y)
+        dx = K.linear_dgrad(g, w).view(ctx.xshape) if ctx.needs_input_grad[0] else None
+        dw = K.linear_wgrad(g, x2)[:n] if ctx.needs_input_grad[1] else None
+        db = K.colsum(g)[:n] if (ctx.has_b and ctx.needs_input_grad[2]) else None
+        return dx, dw, db, None
+
+
+def linear(x, w, b=None, relu: bool = False):
+    return _Linear.apply(x, w, b, relu)
+
+
+class _LayerNorm(torch.autograd.Function):
+    """y = relu?(LN(x)*w + b (+res)) over the trailing w.numel() elements."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, res, relu, eps):
+        xc = x.contiguous()
+        wf, bf = w.reshape(-1).contiguous(), b.reshape(-1).contiguous()
+        rc = None if res is None else res.contiguous()
+        y, mean, rstd = K.layernorm_fwd(xc, wf, bf, eps, rc, relu)
+        ctx.save_for_backward(xc, wf, y if relu else None, mean, rstd)
+        ctx.relu, ctx.has_res, ctx.wshape = relu, res is not None, w.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y, mean, rstd = ctx.saved_tensors
+        dx, dres, dw, db = K.layernorm_bwd(dy.contiguous(), x, y, w, mean, rstd, ctx.relu, ctx.has_res)
+        return dx, dw.view(ctx.wshape), db.view(ctx.wshape), dres, None, None
+
+
+def layer_norm(x, w, b, res=None, relu: bool = False, eps: float = 1e-5):
+    return _LayerNorm.apply(x, w, b, res, relu, eps)
+
+
+class _DwConv(torch.autograd.Function):
+    """Per-anchor depth-wise 3x3 over [N,C,P] planes (Conv2d(N,N,3,padding=1,groups=N) on [1,N,C,P])."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        xc, wc = x.contiguous(), w.contiguous()
+        ctx.save_for_backward(xc, wc)
+        return K.dwconv3x3(xc, wc, b.contiguous())
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        g = dy.contiguous()
+        dx = K.dwconv3x3(g, w, None, flip=True) if ctx.needs_input_grad[0] else None
+        dw, db = K.dwconv3x3_wgrad(g, x)
+        return dx, dw.view_as(w), db
+
+
+def dwconv3x3(x, w, b):
+    return _DwConv.apply(x, w, b)
+
+
+class _RoiPool(torch.autograd.Function):
+    """Lane-anchor ROI pooling on an NHWC map: (fmap [1,h,w,C], xs [1,N,P]) -> roi [1,N,P,C]; also returns the
+    gate's [1,N,C,P] copy (no gradient: the reference feeds the gate a detached tensor, Router4OL.py:275)."""
+
+    @staticmethod
+    def forward(ctx, fmap, xs, ys):
+        fm, xc = fmap.contiguous(), xs.contiguous()
+        roi, roi_cp = K.roi_pool_fwd(fm, xc, ys, with_cp=True)
+        ctx.save_for_backward(fm, xc, ys)
+        ctx.mark_non_differentiable(roi_cp)
+        return roi, roi_cp
+
+    @staticmethod
+    def backward(ctx, droi, _unused):
+        fm, xs, ys = ctx.saved_tensors
+        dmap = torch.zeros_like(fm) if ctx.needs_input_grad[0] else None
+        dxs = K.roi_pool_bwd(droi.contiguous(), fm, xs, ys, dmap, ctx.needs_input_grad[1])
+        return dmap, dxs, None
+
+
+def roi_pool(fmap, xs, ys):
+    return _RoiPool.apply(fmap, xs, ys)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Ops still on ATen device kernels in this round (listed in DESIGN.md "Not yet hand-written"): the per-anchor
+# batched 36x64x128 products of the dynamic head and the 240 x <=40 attention core of branch B.
+# ---------------------------------------------------------------------------------------------------------
+def bmm(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    return torch.bmm(a, b)
+
+
+def attention_core(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, dropout_p: float = 0.0) -> torch.Tensor:
+    """q [L,E], k/v [M,E] -> softmax(q k^T / sqrt(d)) v, heads split along E."""
+    L, e = q.shape
+    d = e // heads
+    qh = q.reshape(L, heads, d).transpose(0, 1) * (1.0 / (d ** 0.5))
+    kh = k.reshape(-1, heads, d).transpose(0, 1)
+    vh = v.reshape(-1, heads, d).transpose(0, 1)
+    att = torch.softmax(torch.bmm(qh, kh.transpose(1, 2)), dim=-1)
+    if dropout_p > 0.0:
+        att = torch.nn.functional.dropout(att, dropout_p)
+    return torch.bmm(att, vh).transpose(0, 1).reshape(L, e)

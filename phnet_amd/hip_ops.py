@@ -11,6 +11,35 @@ from ._lib import check, lib
 
 _WS = {}
 
+# Optional kernel timer (bench.py): when TIMER is a list, every conv/linear GEMM launch is bracketed by two events on
+# the launch stream and recorded as (kernel symbol, algorithmic FLOPs, start event, end event).
+TIMER = None
+
+
+def _gemm_symbol(m, co, k, ws_bytes, dgrad):
+    import ctypes
+    bm, bn, sp = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+    check(lib().phnet_conv2d_plan(m, co, k, ws_bytes, ctypes.byref(bm), ctypes.byref(bn), ctypes.byref(sp)), "phnet_conv2d_plan")
+    return f"conv_igemm_kernel<{bm.value}, {bn.value}, {'true' if dgrad else 'false'}>", sp.value
+
+
+class _Timed:
+    def __init__(self, sym_fn, flops):
+        self.on = TIMER is not None
+        if self.on:
+            self.sym, self.splits = sym_fn()
+            self.flops = flops
+            self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def __enter__(self):
+        if self.on:
+            self.e0.record()
+
+    def __exit__(self, *a):
+        if self.on:
+            self.e1.record()
+            TIMER.append((self.sym, self.splits, self.flops, self.e0, self.e1))
+
 
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
@@ -63,14 +92,16 @@ def lane_nms(rows: torch.Tensor, scores: torch.Tensor, thresh: float, top_k: int
 
 
 # ------------------------------------------------------------------------------------------------ ROI pooling
-def roi_pool_fwd(fmap: torch.Tensor, xs: torch.Tensor, ys: torch.Tensor) -> torch.Tensor:
-    """fmap [B,h,w,64] NHWC, xs [B,N,P], ys [P] -> [B,N,P,64]."""
+def roi_pool_fwd(fmap: torch.Tensor, xs: torch.Tensor, ys: torch.Tensor, with_cp: bool = False):
+    """fmap [B,h,w,64] NHWC, xs [B,N,P], ys [P] -> [B,N,P,64] (and the [B,N,64,P] copy for the gate)."""
     _req(fmap, name="fmap"); _req(xs, name="xs"); _req(ys, name="ys")
     b, h, w, c = fmap.shape
     _, n, p = xs.shape
     out = torch.empty((b, n, p, c), dtype=torch.float32, device=fmap.device)
-    check(lib().phnet_roi_pool_fwd(_ptr(fmap), _ptr(xs), _ptr(ys), _ptr(out), b, n, p, h, w, c, _stream()), "phnet_roi_pool_fwd")
-    return out
+    out_cp = torch.empty((b, n, c, p), dtype=torch.float32, device=fmap.device) if with_cp else None
+    check(lib().phnet_roi_pool_fwd(_ptr(fmap), _ptr(xs), _ptr(ys), _ptr(out), _ptr(out_cp), b, n, p, h, w, c, _stream()),
+          "phnet_roi_pool_fwd")
+    return (out, out_cp) if with_cp else out
 
 
 def roi_pool_bwd(dout, fmap, xs, ys, dmap: Optional[torch.Tensor], need_dxs: bool):
@@ -98,20 +129,24 @@ def conv2d_fwd(x, w, bias, stride: int, pad: int, relu: bool = False, out: Optio
     if out is None:
         out = torch.empty((n, ho, wo, co), dtype=torch.float32, device=x.device)
     ws = workspace(16 * n * ho * wo * co * 4 if n * ho * wo * co < (1 << 22) else 0, x.device)
-    check(lib().phnet_conv2d_fwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(out), n, hi, wi, ci, co, r, s, stride, pad,
-                                 int(relu), _ptr(ws), ws.numel(), _stream()), "phnet_conv2d_fwd")
+    m, k = n * ho * wo, r * s * ci
+    with _Timed(lambda: _gemm_symbol(m, co, k, ws.numel(), False), 2.0 * m * co * k):
+        check(lib().phnet_conv2d_fwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(out), n, hi, wi, ci, co, r, s, stride, pad,
+                                     int(relu), _ptr(ws), ws.numel(), _stream()), "phnet_conv2d_fwd")
     return out
 
 
-def conv2d_dgrad(dy, w, in_hw: Tuple[int, int], stride: int, pad: int):
+def conv2d_dgrad(dy, w, in_hw: Tuple[int, int], stride: int, pad: int, addend: Optional[torch.Tensor] = None):
     _req(dy, name="dy"); _req(w, name="w")
     n = dy.shape[0]
     co, r, s, ci = w.shape
     hi, wi = in_hw
     dx = torch.empty((n, hi, wi, ci), dtype=torch.float32, device=dy.device)
     ws = workspace(16 * n * hi * wi * ci * 4 if n * hi * wi * ci < (1 << 22) else 0, dy.device)
-    check(lib().phnet_conv2d_dgrad(_ptr(dy), _ptr(w), _ptr(dx), n, hi, wi, ci, co, r, s, stride, pad,
-                                   _ptr(ws), ws.numel(), _stream()), "phnet_conv2d_dgrad")
+    m, k = n * hi * wi, r * s * co
+    with _Timed(lambda: _gemm_symbol(m, ci, k, ws.numel(), True), 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * co * r * s * ci):
+        check(lib().phnet_conv2d_dgrad(_ptr(dy), _ptr(w), _ptr(addend), _ptr(dx), n, hi, wi, ci, co, r, s, stride, pad,
+                                       _ptr(ws), ws.numel(), _stream()), "phnet_conv2d_dgrad")
     return dx
 
 
@@ -252,3 +287,58 @@ def colsum(a2d, out: Optional[torch.Tensor] = None, accumulate: bool = False):
     ws = workspace(lib().phnet_colsum_workspace(m, c), a2d.device, 2)
     check(lib().phnet_colsum(_ptr(a2d), _ptr(out), m, c, int(accumulate), _ptr(ws), ws.numel(), _stream()), "phnet_colsum")
     return out
+
+
+# ------------------------------------------------------------------------------------------------ LayerNorm / gate
+def layernorm_fwd(x, w, b, eps: float = 1e-5, res=None, relu: bool = False, save_stats: bool = True):
+    """LayerNorm over the trailing w.numel() elements.  Returns (y, mean, rstd)."""
+    _req(x, name="x")
+    L = w.numel()
+    rows = x.numel() // L
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
+    check(lib().phnet_layernorm_fwd(_ptr(x), _ptr(w), _ptr(b), _ptr(res), _ptr(y), _ptr(mean), _ptr(rstd), rows, L, eps,
+                                    int(relu), _stream()), "phnet_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, y, w, mean, rstd, relu: bool, need_dres: bool = False):
+    """Returns (dx, dres or None, dw, db)."""
+    _req(dy, name="dy")
+    L = w.numel()
+    rows = x.numel() // L
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if need_dres else None
+    dw = torch.empty_like(w)
+    db = torch.empty_like(w)
+    ws = workspace(lib().phnet_layernorm_bwd_workspace(rows, L), x.device, 2)
+    check(lib().phnet_layernorm_bwd(_ptr(dy), _ptr(x), _ptr(y), _ptr(w), _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dres),
+                                    _ptr(dw), _ptr(db), rows, L, int(relu), 0, _ptr(ws), ws.numel(), _stream()),
+          "phnet_layernorm_bwd")
+    return dx, dres, dw, db
+
+
+def dwconv3x3(x, w, bias, flip: bool = False):
+    """x [N,C,P] planes, w [N,3,3] (or [N,1,3,3]), bias [N] or None."""
+    _req(x, name="x"); _req(w, name="w")
+    n, c, p = x.shape
+    y = torch.empty_like(x)
+    check(lib().phnet_dwconv3x3(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), n, c, p, int(flip), _stream()), "phnet_dwconv3x3")
+    return y
+
+
+def dwconv3x3_wgrad(dy, x):
+    _req(dy, name="dy")
+    n, c, p = x.shape
+    dw = torch.empty((n, 1, 3, 3), dtype=torch.float32, device=x.device)
+    db = torch.empty((n,), dtype=torch.float32, device=x.device)
+    check(lib().phnet_dwconv3x3_wgrad(_ptr(dy), _ptr(x), _ptr(dw), _ptr(db), n, c, p, 0, _stream()), "phnet_dwconv3x3_wgrad")
+    return dw, db
+
+
+def relu_bwd(dy, y):
+    _req(dy, name="dy")
+    dx = torch.empty_like(dy)
+    check(lib().phnet_relu_bwd(_ptr(dy), _ptr(y), _ptr(dx), dy.numel(), _stream()), "phnet_relu_bwd")
+    return dx

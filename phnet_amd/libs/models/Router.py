@@ -1,0 +1,44 @@
+"""Adaptive routing gate (reference: libs/models/Router.py:39-81) on the HIP LayerNorm / depth-wise / GEMM kernels."""
+import copy
+
+import torch
+import torch.nn as nn
+
+from phnet_amd import functional as PF
+
+
+class AdaptiveRouter4Lane(nn.Module):
+    def __init__(self, num_priors=240, features_channels=64, num_points=36, out_channels=1, reduction=4, stages=3):
+        super().__init__()
+        width = features_channels * num_points
+        self.inp = width // reduction
+        mlp = nn.Sequential(nn.Linear(width, self.inp), nn.ReLU(), nn.Linear(self.inp, out_channels), nn.ReLU())
+        gain = nn.init.calculate_gain("tanh")
+        for m in mlp:
+            if isinstance(m, nn.Linear):
+                nn.init.xavier_uniform_(m.weight, gain=gain)
+        self.layers = nn.ModuleList(copy.deepcopy(mlp) for _ in range(stages))
+        norm = nn.LayerNorm([features_channels, num_points])
+        self.pre_norm = nn.ModuleList(copy.deepcopy(norm) for _ in range(stages))
+
+        def dw():
+            return nn.Conv2d(num_priors, num_priors, 3, padding=1, groups=num_priors)
+        block = nn.Sequential(dw(), copy.deepcopy(norm), nn.ReLU(), dw(), copy.deepcopy(norm))
+        net = nn.ModuleList(copy.deepcopy(block) for _ in range(4))
+        self.DWNets = nn.ModuleList(copy.deepcopy(net) for _ in range(stages))
+
+    def forward(self, xs: torch.Tensor, stage: int, thres: float = 0.5) -> torch.Tensor:
+        """xs [1,N,C,P] (detached by the caller) -> [1,N,1] in [0.5, 1)."""
+        b, n, c, p = xs.shape
+        assert b == 1
+        pn = self.pre_norm[stage]
+        x = PF.layer_norm(xs.reshape(n, c, p), pn.weight, pn.bias, eps=pn.eps)
+        for blk in self.DWNets[stage]:
+            y = PF.dwconv3x3(x, blk[0].weight, blk[0].bias)
+            y = PF.layer_norm(y, blk[1].weight, blk[1].bias, relu=True, eps=blk[1].eps)
+            y = PF.dwconv3x3(y, blk[3].weight, blk[3].bias)
+            x = PF.layer_norm(y, blk[4].weight, blk[4].bias, res=x, relu=True, eps=blk[4].eps)
+        mlp = self.layers[stage]
+        h = PF.linear(x.reshape(n, c * p), mlp[0].weight, mlp[0].bias, relu=True)
+        h = PF.linear(h, mlp[2].weight, mlp[2].bias, relu=True)          # ReLU before the sigmoid (Router.py:45-48)
+        return torch.sigmoid(h).view(1, n, -1)

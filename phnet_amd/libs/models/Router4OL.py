@@ -1,0 +1,306 @@
+"""PHNet clip model on the MI355X HIP kernels, behind the reference's module API.
+
+Drop-in for `libs.models.Router4OL` (reference: libs/models/Router4OL.py): same class names, constructor signatures,
+state_dict keys/shapes, `forward(inputs: dict)` contract (train: summed clip loss; eval: {'lane_lines': [...]}).
+Parameters live in ordinary nn.Module containers; every contraction / normalisation / pooling / NMS on the path runs
+through phnet_amd.hip_ops (C-ABI -> gfx950 kernels).  There is no CPU path: tensors must be on the GPU.
+"""
+import copy
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from phnet_amd import functional as PF
+from phnet_amd.trunk import encoder_forward
+from ..ops import nms
+from ..utils.lane import Lane
+from .fpn import FPN
+from .resnet import ResNetWrapper
+from .Router import AdaptiveRouter4Lane
+from .utils.dynamic_head import DynamicConv
+from .utils.transformer import TransformerDecoder, TransformerDecoderLayer
+
+
+def LinearModule(hidden_dim):
+    return nn.ModuleList([nn.Linear(hidden_dim, hidden_dim), nn.ReLU(inplace=False)])
+
+
+class PositionalEncodingLearned(nn.Module):
+    def __init__(self, num_embeddings, num_pos_feats=256):
+        super().__init__()
+        self.embed = nn.Embedding(num_embeddings, num_pos_feats)
+        nn.init.uniform_(self.embed.weight)
+
+
+class Encoder(nn.Module):
+    """ResNet trunk + FPN; returns (P3, P4, P5) as NHWC tensors [T,h,w,64] (internal layout of the head)."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.backbone = ResNetWrapper(**cfg.backbone)
+        self.neck = FPN(**cfg.neck) if cfg.haskey("neck") else None
+        if self.neck is None:
+            raise NotImplementedError("the hot path needs the FPN neck (options4OL.py:58-61)")
+
+    def forward(self, batch):
+        frames = batch["img"] if isinstance(batch, dict) else batch
+        return encoder_forward(self, frames)
+
+
+class DetNetV2(nn.Module):
+    """Anchor-based lane head: ROI pooling along anchors, routing gate, dynamic head, branch A (per-frame MLPs),
+    branch B (cross-frame transformer), three coarse-to-fine refinement stages."""
+
+    def __init__(self, prior_feat_channels=64, fc_hidden_dim=64, num_fc=2, refine_layers=3, sample_points=36, cfg=None):
+        super().__init__()
+        self.cfg = cfg
+        self.img_w, self.img_h = cfg.img_w, cfg.img_h
+        self.n_strips, self.n_offsets = cfg.num_points - 1, cfg.num_points
+        self.num_priors = cfg.num_priors
+        self.sample_points, self.refine_layers = sample_points, refine_layers
+        self.fc_hidden_dim = self.reg_hidden_dim = fc_hidden_dim
+        self.prior_feat_channels = prior_feat_channels
+        idx = (torch.linspace(0, 1, steps=sample_points, dtype=torch.float32) * self.n_strips).long()
+        self.register_buffer("sample_x_indexs", idx)
+        self.register_buffer("prior_feat_ys", torch.flip(1 - idx.float() / self.n_strips, dims=[-1]))
+        self.register_buffer("prior_ys", torch.linspace(1, 0, steps=self.n_offsets, dtype=torch.float32))
+        self.prior_embeddings = nn.Embedding(self.num_priors, 3)
+        with torch.no_grad():
+            self.prior_embeddings.weight.copy_(self._initial_anchors())
+            pri, on_map = self._expand_anchors(self.prior_embeddings.weight)
+        self.register_buffer("priors", pri)
+        self.register_buffer("priors_on_featmap", on_map)
+
+        def tower(width):
+            mods = []
+            for _ in range(num_fc):
+                mods += [*LinearModule(width)]
+            return nn.ModuleList(mods)
+        c = fc_hidden_dim
+        self.reg_modules, self.cls_modules, self.iou_modules = tower(c), tower(c), tower(c)
+        self.reg_layers, self.cls_layers, self.iou_layers = nn.Linear(c, 4), nn.Linear(c, 2), nn.Linear(c, self.n_offsets)
+        self.reg_modules_sec, self.cls_modules_sec, self.iou_modules_sec = tower(2 * c), tower(2 * c), tower(2 * c)
+        self.reg_layers_sec, self.cls_layers_sec = nn.Linear(2 * c, 4), nn.Linear(2 * c, 2)
+        self.iou_layers_sec = nn.Linear(2 * c, self.n_offsets)
+        for lin in (self.cls_layers, self.reg_layers, self.cls_layers_sec, self.reg_layers_sec):
+            for p in lin.parameters():
+                nn.init.normal_(p, mean=0., std=1e-3)
+        layer = TransformerDecoderLayer(d_model=2 * c, nhead=8, dim_feedforward=256, dropout=0.1, activation="gelu",
+                                        normalize_before=True)
+        self.transformer_Dec = TransformerDecoder(layer, 2, nn.LayerNorm(2 * c))
+        self.PositionEmbedding = PositionalEncodingLearned(num_embeddings=self.num_priors, num_pos_feats=c)
+        head = DynamicConv(feat_size=sample_points, inplanes=c, early_return=False)
+        self.DHead_series = nn.ModuleList(copy.deepcopy(head) for _ in range(refine_layers))
+        self.pro_embedding = nn.Embedding(self.num_priors, prior_feat_channels)
+        self.router = AdaptiveRouter4Lane(num_priors=self.num_priors, features_channels=prior_feat_channels,
+                                          num_points=sample_points, out_channels=1, reduction=4, stages=refine_layers)
+
+    # ---- anchors ---------------------------------------------------------------------------------------------
+    def _initial_anchors(self) -> torch.Tensor:
+        n = self.num_priors
+        quarter, half = n // 4, n // 2
+        side, bottom = 0.8 / (quarter // 2 - 1), 0.5 / (quarter // 2 + 1)
+        rows = []
+        for i in range(n):
+            even = i % 2 == 0
+            if i < quarter:
+                rows.append(((i // 2) * side, 0., 0.16 if even else 0.32))
+            elif i < half:
+                rows.append((0., ((i - quarter) // 2 + 1) * bottom, 0.2 if even else 0.4))
+            elif i < half + quarter:
+                rows.append((0., ((i - half) // 2 + 1) * bottom + 0.5, 0.6 if even else 0.8))
+            else:
+                rows.append((((i - half - quarter) // 2) * side, 1., 0.68 if even else 0.84))
+        return torch.tensor(rows, dtype=torch.float32)
+
+    def _line_xs(self, sy, sx, theta):
+        return (sx * (self.img_w - 1) + ((1 - self.prior_ys - sy) * self.img_h / torch.tan(theta * math.pi + 1e-5))) / (self.img_w - 1)
+
+    def _expand_anchors(self, emb: torch.Tensor):
+        xs = self._line_xs(emb[:, 0:1], emb[:, 1:2], emb[:, 2:3])
+        z = emb.new_zeros(emb.shape[0], 1)
+        pri = torch.cat([z, z, emb, z, xs], dim=1)
+        return pri, pri[:, 6 + self.sample_x_indexs]
+
+    def generate_priors_from_embeddings(self):
+        return self._expand_anchors(self.prior_embeddings.weight)
+
+    # ---- the two branches --------------------------------------------------------------------------------------
+    @staticmethod
+    def _tower(mods, x):
+        for m in mods:
+            if isinstance(m, nn.Linear):
+                x = PF.linear(x, m.weight, m.bias, relu=True)      # every Linear of a tower is followed by its ReLU
+        return x
+
+    def _update(self, priors, cls, reg, off):
+        syx_t = priors[..., 2:5] + torch.tanh(reg[..., :3])
+        xs = self._line_xs(syx_t[..., 0:1], syx_t[..., 1:2], syx_t[..., 2:3])
+        lines = torch.cat([cls, syx_t, reg[..., 3:4], xs], dim=-1)
+        return torch.cat([cls, syx_t, reg[..., 3:4], xs + off], dim=-1), lines
+
+    def _branch(self, feat, priors, sec: bool):
+        s = "_sec" if sec else ""
+        g = lambda name: getattr(self, name + s)                                     # noqa: E731
+        cls = PF.linear(self._tower(g("cls_modules"), feat), g("cls_layers").weight, g("cls_layers").bias)
+        reg = PF.linear(self._tower(g("reg_modules"), feat), g("reg_layers").weight, g("reg_layers").bias)
+        off = PF.linear(self._tower(g("iou_modules"), feat), g("iou_layers").weight, g("iou_layers").bias)
+        n = self.num_priors
+        return self._update(priors, cls.reshape(1, n, 2), reg.reshape(1, n, 4), off.reshape(1, n, self.n_offsets))
+
+    def forward_first(self, decode_feat_l, priors):
+        return self._branch(decode_feat_l, priors, False)
+
+    def forward_second(self, last_cut, attn_feat, stage, priors):
+        """attn_feat [N,1,128]; last_cut [M,1,128] or None."""
+        if last_cut is not None and last_cut.shape[0] != 0:
+            feat = self.transformer_Dec(tgt=attn_feat, memory=last_cut)
+        else:
+            feat = attn_feat
+        return self._branch(feat.reshape(1, self.num_priors, -1), priors, True)
+
+    # ---- one refinement stage / one frame ---------------------------------------------------------------------
+    def stage_forward(self, fmap, stage, priors, on_map, pro_feat, memory):
+        """fmap [1,h,w,C] NHWC level of this stage; priors [1,N,6+S]; on_map [1,N,P]; pro_feat [1,N,C];
+        memory [M,1,2C] or None.  Returns dict(pred_a, lines_a, pred_b, lines_b, attn, gate, local)."""
+        roi, roi_cp = PF.roi_pool(fmap, on_map, self.prior_feat_ys)                  # [1,N,P,C], [1,N,C,P]
+        gate = self.router(roi_cp, stage)                                            # [1,N,1]
+        local = self.DHead_series[stage](pro_feat, roi)                              # [1,N,C]
+        pred_a, lines_a = self.forward_first(local, priors)
+        pos = self.PositionEmbedding.embed.weight.unsqueeze(1)                       # [N,1,C]
+        attn = torch.cat([local.transpose(0, 1), pos], dim=-1)                       # [N,1,2C]
+        pred_b, lines_b = self.forward_second(memory, attn, stage, priors)
+        return dict(pred_a=pred_a, lines_a=lines_a, pred_b=pred_b, lines_b=lines_b, attn=attn, gate=gate, local=local)
+
+    def forward(self, x, last_cuts=None):
+        """x = (P3, P4, P5) NHWC [1,h,w,C] for ONE frame; last_cuts = list over remembered frames of per-stage tokens."""
+        levels = list(x)[::-1]
+        last_cuts = last_cuts or []
+        if self.training:
+            self.priors, self.priors_on_featmap = self.generate_priors_from_embeddings()
+        priors, on_map = self.priors.unsqueeze(0), self.priors_on_featmap.unsqueeze(0)
+        pro_feat = self.pro_embedding.weight.unsqueeze(0)
+        out_a, out_b, attn_feats, gates = [], [], [], []
+        for stage in range(self.refine_layers):
+            mem = torch.cat([fr[stage] for fr in last_cuts], dim=0) if len(last_cuts) else None
+            r = self.stage_forward(levels[stage], stage, priors, on_map, pro_feat, mem)
+            pro_feat = r["local"].detach()
+            out_a.append(r["pred_a"]); out_b.append(r["pred_b"]); attn_feats.append(r["attn"]); gates.append(r["gate"])
+            if stage != self.refine_layers - 1:
+                w = r["gate"].detach()
+                priors = ((1 - w) * r["lines_a"] + w * r["lines_b"]).detach()
+                on_map = priors[..., 6 + self.sample_x_indexs].contiguous()
+        return {"predictions_fir": out_a, "predictions_sec": out_b}, attn_feats, gates
+
+    # ---- decode ---------------------------------------------------------------------------------------------------
+    def predictions_to_pred(self, predictions, ori_img_h=None, cut_height=0):
+        """Kept lanes [k,6+S] (length already in strips) -> list of Lane.  Host-side, float64 like the reference
+        (Router4OL.py:394-435) but without mutating the prior_ys buffer."""
+        rows = predictions.detach().cpu()
+        ys_all = self.prior_ys.detach().cpu().double()
+        lanes = []
+        for row in rows:
+            xs = row[6:].clone()
+            start = min(max(0, int(round(row[2].item() * self.n_strips))), self.n_strips)
+            end = min(start + int(round(row[5].item())) - 1, self.n_offsets - 1)
+            inside = ((xs[:start] >= 0.) & (xs[:start] <= 1.)).numpy()
+            outside = ~(inside[::-1].cumprod()[::-1].astype(bool))
+            xs[end + 1:] = -2
+            xs[:start][torch.from_numpy(outside.copy())] = -2
+            sel = xs >= 0
+            lx, ly = xs[sel].flip(0).double(), ys_all[sel].flip(0)
+            if lx.numel() <= 1:
+                continue
+            lanes.append(Lane(points=torch.stack([lx, ly], dim=1).numpy(),
+                              metadata={"start_x": row[3], "start_y": row[2], "conf": row[1]}))
+        return lanes
+
+    def get_lanes(self, output, org_size=None, crop_size=0, as_lanes=True):
+        """output [B,N,6+S] blended lines -> (decoded per batch item, keep_inds, keep) as in Router4OL.py:437-479."""
+        decoded, keep_inds, keep = [], None, []
+        for predictions in output:
+            scores = torch.softmax(predictions[:, :2], dim=1)[:, 1]
+            keep_inds = scores >= self.cfg.test_parameters.conf_threshold
+            cand = predictions[keep_inds]
+            keep = []
+            if cand.shape[0] == 0:
+                decoded.append([])
+                continue
+            rows = torch.cat([cand[:, :4], cand[:, 5:]], dim=-1).detach().clone()
+            rows[:, 3] = rows[:, 3] * (self.img_w - 1)
+            rows[:, 4] = rows[:, 4] * self.n_strips
+            rows[:, 5:] = rows[:, 5:] * (self.img_w - 1)
+            keep, num_to_keep, _ = nms(rows.contiguous(), scores[keep_inds].contiguous(),
+                                       overlap=self.cfg.test_parameters.nms_thres, top_k=self.cfg.max_lanes)
+            keep = keep[:int(num_to_keep)]
+            kept = cand[keep].clone()
+            if kept.shape[0] == 0:
+                decoded.append([])
+                continue
+            kept[:, 5] = torch.round(kept[:, 5] * self.n_strips)
+            decoded.append(self.predictions_to_pred(kept) if as_lanes else kept)
+        return decoded, keep_inds, keep
+
+
+class RouterOL(nn.Module):
+    def __init__(self, cfg, criterion=None):
+        super().__init__()
+        self.backbone = Encoder(cfg=cfg)
+        self.detNet = DetNetV2(cfg=cfg)
+        self.criterion = criterion
+        self.save_freq_max = cfg.save_freq_max
+        self.crop_size = cfg.dscfg.crop_size
+        self.org_size = (cfg.dscfg.org_height, cfg.dscfg.org_width)
+
+    def forward(self, inputs: dict):
+        frame, lanes = inputs.values()
+        if not frame.is_cuda:
+            raise RuntimeError("phnet_amd runs on the GPU only: move the model and the clip to cuda")
+        T = frame.shape[0]
+        feats = self.backbone(frame)                                           # 3 x [T,h,w,C] NHWC
+        last_cuts = []
+        total_loss = 0.0
+        clip_outputs = {"lane_lines": []}
+        for t in range(T):
+            cur = tuple(f[t:t + 1] for f in feats)
+            outputs, cur_cut, gates = self.detNet(cur, last_cuts)
+            if self.training:
+                matched, frame_loss = self.criterion(outputs, lanes[t:t + 1], gates)
+                total_loss = total_loss + frame_loss
+            else:
+                d = torch.stack(gates, dim=0).mean(dim=0)
+                lines = outputs["predictions_sec"][-1] * d + outputs["predictions_fir"][-1] * (1 - d)
+                lane_lines, keep_inds, keep = self.detNet.get_lanes(lines, self.org_size, self.crop_size)
+                clip_outputs["lane_lines"].append(lane_lines[0])
+            with torch.no_grad():
+                if self.training:
+                    last_cuts.append(self.saveMemory(matched, cur_cut))
+                else:
+                    last_cuts.append(self.saveMemory4Test(keep_inds, keep, cur_cut))
+                if t >= self.save_freq_max:
+                    last_cuts.pop(0)
+        return total_loss if self.training else clip_outputs
+
+    @staticmethod
+    def _tokens(feat, mask):
+        return torch.cat([feat[mask], feat[~mask].mean(dim=0, keepdim=True)], dim=0)
+
+    def saveMemory(self, matched_indices, curr_cut):
+        memory = []
+        for matched, feat in zip(matched_indices, curr_cut):
+            mask = torch.zeros(self.detNet.num_priors, dtype=torch.bool, device=feat.device)
+            if len(matched):
+                mask[torch.as_tensor(matched, device=feat.device)] = True
+            memory.append(self._tokens(feat.detach(), mask))
+        return memory
+
+    def saveMemory4Test(self, keep_inds, keep, curr_cut):
+        memory = []
+        for feat in curr_cut:
+            mask = torch.zeros(feat.shape[0], dtype=torch.bool, device=feat.device)
+            if len(keep):
+                mask[torch.where(keep_inds)[0][keep]] = True
+            memory.append(self._tokens(feat.detach(), mask))
+        return memory

@@ -1,0 +1,69 @@
+"""Cross-frame transformer decoder of branch B (reference: libs/models/utils/transformer.py:92-129, 236-298;
+pre-norm layers, GELU feed-forward, nn.MultiheadAttention parameter layout)."""
+import copy
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from phnet_amd import functional as PF
+
+
+def _attention(mha: nn.MultiheadAttention, q_in: torch.Tensor, kv_in: torch.Tensor, training: bool) -> torch.Tensor:
+    """q_in [L,E], kv_in [M,E] (batch 1, no masks) -> [L,E]."""
+    e, h = mha.embed_dim, mha.num_heads
+    w, b = mha.in_proj_weight, mha.in_proj_bias
+    q = PF.linear(q_in, w[:e], b[:e])
+    if q_in is kv_in:
+        kv = PF.linear(kv_in, w[e:], b[e:])
+        k, v = kv[:, :e], kv[:, e:]
+    else:
+        k = PF.linear(kv_in, w[e:2 * e], b[e:2 * e])
+        v = PF.linear(kv_in, w[2 * e:], b[2 * e:])
+    out = PF.attention_core(q, k, v, h, mha.dropout if training else 0.0)
+    return PF.linear(out, mha.out_proj.weight, mha.out_proj.bias)
+
+
+class TransformerDecoderLayer(nn.Module):
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, activation="relu", normalize_before=False):
+        super().__init__()
+        if not normalize_before or activation != "gelu":
+            raise NotImplementedError("the hot path uses pre-norm GELU layers (Router4OL.py:100-103)")
+        self.self_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.multihead_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.dropout = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1, self.norm2, self.norm3 = nn.LayerNorm(d_model), nn.LayerNorm(d_model), nn.LayerNorm(d_model)
+        self.dropout1, self.dropout2, self.dropout3 = nn.Dropout(dropout), nn.Dropout(dropout), nn.Dropout(dropout)
+        self.normalize_before = normalize_before
+
+    def forward(self, tgt: torch.Tensor, memory: torch.Tensor) -> torch.Tensor:
+        """tgt [L,E], memory [M,E]."""
+        h = PF.layer_norm(tgt, self.norm1.weight, self.norm1.bias, eps=self.norm1.eps)
+        tgt = tgt + self.dropout1(_attention(self.self_attn, h, h, self.training))
+        h = PF.layer_norm(tgt, self.norm2.weight, self.norm2.bias, eps=self.norm2.eps)
+        tgt = tgt + self.dropout2(_attention(self.multihead_attn, h, memory, self.training))
+        h = PF.layer_norm(tgt, self.norm3.weight, self.norm3.bias, eps=self.norm3.eps)
+        h = self.dropout(F.gelu(PF.linear(h, self.linear1.weight, self.linear1.bias)))
+        return tgt + self.dropout3(PF.linear(h, self.linear2.weight, self.linear2.bias))
+
+
+class TransformerDecoder(nn.Module):
+    def __init__(self, decoder_layer, num_layers, norm=None, return_intermediate=False):
+        super().__init__()
+        self.layers = nn.ModuleList(copy.deepcopy(decoder_layer) for _ in range(num_layers))
+        self.num_layers = num_layers
+        self.norm = copy.deepcopy(norm)
+        self.return_intermediate = return_intermediate
+
+    def forward(self, tgt: torch.Tensor, memory: torch.Tensor) -> torch.Tensor:
+        """tgt [L,1,E] or [L,E]; memory [M,1,E] or [M,E]; returns the same rank as tgt."""
+        shape = tgt.shape
+        x, mem = tgt.reshape(shape[0], shape[-1]), memory.reshape(memory.shape[0], memory.shape[-1])
+        for layer in self.layers:
+            x = layer(x, mem)
+        if self.norm is not None:
+            x = PF.layer_norm(x, self.norm.weight, self.norm.bias, eps=self.norm.eps)
+        return x.reshape(shape)

@@ -1,0 +1,35 @@
+"""Synthetic clips / lane labels in the reference's input contract: frames float32 N(0,1)
+[T,3,H,W]; labels [T,4,6+S] in the layout of libs/dataset/openlane/transforms.py:264-297
+(neg flag, pos flag, start_y, start_x/(W-1), theta, len/n_strips, S x-coordinates in pixels, -1e5 = invalid)."""
+import math
+
+import numpy as np
+import torch
+
+
+def make_clip(img_h: int, img_w: int, T: int, seed: int = 3407) -> torch.Tensor:
+    r = np.random.default_rng([seed, T, img_h, img_w])
+    return torch.from_numpy(r.standard_normal((T, 3, img_h, img_w), dtype=np.float32))
+
+
+def make_targets(img_h: int, img_w: int, T: int, num_points: int = 36, n_lanes: int = 3, max_lanes: int = 4) -> torch.Tensor:
+    S, W, H = num_points, img_w, img_h
+    strip = H / (S - 1)
+    out = np.full((T, max_lanes, 6 + S), -1e5, dtype=np.float32)
+    out[:, :, 0], out[:, :, 1] = 1, 0
+    x0s, slopes = (0.2, 0.45, 0.7, 0.85), (4.0, 0.5, -4.0, -6.0)
+    for t in range(T):
+        for j in range(min(n_lanes, max_lanes)):
+            xs = x0s[j] * W + 5.0 * t + slopes[j] * np.arange(S)
+            valid = (xs >= 0) & (xs < W)
+            n = int(np.argmin(valid)) if not valid.all() else S
+            n = min(n, S - 4 - j)
+            xs = xs[:n]
+            th = [math.atan(i * strip / (xs[i] - xs[0] + 1e-5)) / math.pi for i in range(1, n)]
+            th = [v if v > 0 else 1 - abs(v) for v in th]
+            out[t, j, 0], out[t, j, 1], out[t, j, 2] = 0, 1, 0.0
+            out[t, j, 3] = xs[0] / (W - 1)
+            out[t, j, 4] = sum(th) / len(th)
+            out[t, j, 5] = n / (S - 1)
+            out[t, j, 6:6 + n] = xs
+    return torch.from_numpy(out)

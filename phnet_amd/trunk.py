@@ -1,0 +1,177 @@
+"""Hand-scheduled forward/backward of the ResNet trunk + FPN neck on the HIP kernels (NHWC, fp32 MFMA).
+
+One autograd node for the whole encoder: the schedule below launches the C-ABI kernels directly and keeps its
+own tape, so PyTorch's autograd only sees (frames, parameters) -> (P3, P4, P5).  Mirrors, as a schedule:
+  libs/models/resnet.py:79-95 (BasicBlock), :293-307 (ResNet.forward)
+  libs/models/fpn.py:109-163  (FPN.forward: drop layer1, 1x1 laterals, nearest top-down add, 3x3 outputs)
+The nn.Conv2d / nn.BatchNorm2d objects handed in are parameter containers only (state_dict compatibility);
+their own forward is never called.  Under nn.SyncBatchNorm containers (trainOL.py:141) the batch statistics are
+all-reduced across ranks before normalisation.
+"""
+from typing import List
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from . import hip_ops as K
+
+
+def ohwi(w: torch.Tensor) -> torch.Tensor:
+    """OIHW-logical conv weight -> contiguous [Co,R,S,Ci] view (free when the parameter is channels_last)."""
+    return w.detach().permute(0, 2, 3, 1).contiguous()
+
+
+def oihw_grad(dw_ohwi: torch.Tensor) -> torch.Tensor:
+    return dw_ohwi.permute(0, 3, 1, 2)
+
+
+def _sync_bn(bn) -> bool:
+    return isinstance(bn, nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+class _ConvBN:
+    """Tape record of conv -> BN(+residual)(+ReLU)."""
+    __slots__ = ("conv", "bn", "stride", "pad", "x_in", "w", "c", "y", "sm", "si", "relu", "has_res")
+
+
+def _conv_bn(tape: list, x, conv: nn.Conv2d, bn, training: bool, relu: bool, residual=None, w_override=None):
+    rec = _ConvBN()
+    rec.conv, rec.bn = conv, bn
+    rec.stride, rec.pad = conv.stride[0], conv.padding[0]
+    rec.w = w_override if w_override is not None else ohwi(conv.weight)
+    rec.x_in = x
+    rec.c = K.conv2d_fwd(x, rec.w, None, rec.stride, rec.pad)
+    if training and _sync_bn(bn):
+        raise NotImplementedError("SyncBatchNorm statistics exchange is implemented in phnet_amd.parallel (see DESIGN.md)")
+    rec.y, rec.sm, rec.si = K.bn_fwd(rec.c, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
+                                     training, bn.eps, bn.momentum if bn.momentum is not None else 0.1, residual, relu)
+    if training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    rec.relu, rec.has_res = relu, residual is not None
+    tape.append(rec)
+    return rec.y
+
+
+class EncoderFunction(torch.autograd.Function):
+    """(frames NCHW, *encoder parameters) -> (P3, P4, P5) as NHWC tensors."""
+
+    @staticmethod
+    def forward(ctx, enc, training: bool, frames: torch.Tensor, *params):
+        model, neck = enc.backbone.model, enc.neck
+        tape = []
+        x = K.nchw3_to_nhwc4(frames.contiguous())
+        w_stem = K.pad_channels(ohwi(model.conv1.weight).view(-1, 3), 4).view(model.conv1.out_channels, 7, 7, 4)
+        y = _conv_bn(tape, x, model.conv1, model.bn1, training, relu=True, w_override=w_stem)
+        stem_shape = tuple(y.shape)
+        y, argmax = K.maxpool_fwd(y)
+        stages = []
+        for name in ("layer1", "layer2", "layer3", "layer4"):
+            for blk in getattr(model, name):
+                h = _conv_bn(tape, y, blk.conv1, blk.bn1, training, relu=True)
+                if blk.downsample is not None:
+                    idn = _conv_bn(tape, y, blk.downsample[0], blk.downsample[1], training, relu=False)
+                else:
+                    idn = y
+                y = _conv_bn(tape, h, blk.conv2, blk.bn2, training, relu=True, residual=idn)
+            stages.append(y)
+        feats = stages[-3:]                                        # fpn.py:113-115 drops layer1
+        lat_w = [ohwi(m.conv.weight) for m in neck.lateral_convs]
+        out_w = [ohwi(m.conv.weight) for m in neck.fpn_convs]
+        lats = [K.conv2d_fwd(f, w, m.conv.bias.detach(), 1, 0) for f, w, m in zip(feats, lat_w, neck.lateral_convs)]
+        for i in (2, 1):
+            K.upsample_add_(lats[i - 1], lats[i])
+        outs = [K.conv2d_fwd(l, w, m.conv.bias.detach(), 1, 1) for l, w, m in zip(lats, out_w, neck.fpn_convs)]
+        if training:
+            ctx.enc, ctx.tape, ctx.argmax, ctx.stem_shape = enc, tape, argmax, stem_shape
+            ctx.feats, ctx.lats, ctx.lat_w, ctx.out_w = feats, lats, lat_w, out_w
+            ctx.index = {id(p): i for i, p in enumerate(enc.parameters())}
+            ctx.nparams = len(params)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, d3, d4, d5):
+        enc = ctx.enc
+        model, neck = enc.backbone.model, enc.neck
+        grads: List = [None] * ctx.nparams
+
+        def put(p, g):
+            grads[ctx.index[id(p)]] = g
+
+        # ---- FPN ------------------------------------------------------------------------------------------
+        douts = [d.contiguous() for d in (d3, d4, d5)]
+        dl = []
+        for i in range(3):
+            m = neck.fpn_convs[i].conv
+            put(m.weight, oihw_grad(K.conv2d_wgrad(douts[i], ctx.lats[i], ctx.out_w[i].shape, 1, 1)))
+            put(m.bias, K.colsum(douts[i].view(-1, douts[i].shape[-1])))
+            dl.append(K.conv2d_dgrad(douts[i], ctx.out_w[i], tuple(ctx.lats[i].shape[1:3]), 1, 1))
+        for i in (1, 2):
+            K.upsample_add_bwd_(dl[i - 1], dl[i])
+        dstage = []
+        for i in range(3):
+            m = neck.lateral_convs[i].conv
+            put(m.weight, oihw_grad(K.conv2d_wgrad(dl[i], ctx.feats[i], ctx.lat_w[i].shape, 1, 0)))
+            put(m.bias, K.colsum(dl[i].view(-1, dl[i].shape[-1])))
+            dstage.append(K.conv2d_dgrad(dl[i], ctx.lat_w[i], tuple(ctx.feats[i].shape[1:3]), 1, 0))
+        # ---- trunk, last block first ----------------------------------------------------------------------
+        tape = ctx.tape
+        pos = len(tape)
+
+        def bn_back(rec, dy, dres=None, dres_acc=False):
+            dx, dg, db = K.bn_bwd(dy, rec.c, rec.y, rec.sm, rec.si, rec.bn.weight.detach(), rec.relu, dres, dres_acc)
+            put(rec.bn.weight, dg)
+            put(rec.bn.bias, db)
+            return dx
+
+        def conv_back(rec, dc, need_dx=True, addend=None):
+            dw = K.conv2d_wgrad(dc, rec.x_in, rec.w.shape, rec.stride, rec.pad)
+            if rec.conv is model.conv1:
+                dw = K.pad_channels(dw.view(-1, 4), 3).view(dw.shape[0], 7, 7, 3)
+            put(rec.conv.weight, oihw_grad(dw))
+            if not need_dx:
+                return None
+            return K.conv2d_dgrad(dc, rec.w, tuple(rec.x_in.shape[1:3]), rec.stride, rec.pad, addend)
+
+        dy = None
+        stage_names = ("layer4", "layer3", "layer2", "layer1")
+        for si, name in enumerate(stage_names):
+            # gradient arriving at this stage's output: from the neck (stages 2..4) and from the next stage
+            extra = dstage[2 - si] if si < 3 else None
+            if dy is None:
+                dy = extra
+            elif extra is not None:
+                dy = dy + extra
+            for blk in reversed(list(getattr(model, name))):
+                has_ds = blk.downsample is not None
+                rec2 = tape[pos - 1]
+                recd = tape[pos - 2] if has_ds else None
+                rec1 = tape[pos - 3] if has_ds else tape[pos - 2]
+                pos -= 3 if has_ds else 2
+                dres = torch.empty_like(rec2.c)
+                dc2 = bn_back(rec2, dy, dres)                     # dres = relu-masked gradient for the identity path
+                dh = conv_back(rec2, dc2)
+                dc1 = bn_back(rec1, dh)
+                if has_ds:
+                    dcd = bn_back(recd, dres)
+                    dxd = conv_back(recd, dcd)
+                    dy = conv_back(rec1, dc1, addend=dxd)
+                else:
+                    dy = conv_back(rec1, dc1, addend=dres)
+        # ---- stem -------------------------------------------------------------------------------------------
+        rec = tape[0]
+        dpool = K.maxpool_bwd(dy, ctx.argmax, ctx.stem_shape)
+        dc = bn_back(rec, dpool)
+        conv_back(rec, dc, need_dx=False)
+        ctx.tape = ctx.feats = ctx.lats = None
+        return (None, None, None, *grads)
+
+
+def encoder_forward(enc, frames: torch.Tensor):
+    """enc: the Encoder container (backbone.model = ResNet container, neck = FPN container)."""
+    params = [p for p in enc.parameters()]
+    training = enc.training and torch.is_grad_enabled()
+    if enc.training and not training:
+        # train-mode statistics without a tape (e.g. under no_grad): still the training arithmetic
+        return EncoderFunction.apply(enc, True, frames, *[p.detach() for p in params])
+    return EncoderFunction.apply(enc, enc.training, frames, *params)

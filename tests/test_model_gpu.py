@@ -1,0 +1,242 @@
+"""Parity of the HIP-backed model (phnet_amd.libs.*) on a real MI355X against
+ (a) the golden fixtures produced by the reference's own Python (tests/golden/*.npz), end to end, and
+ (b) the CPU oracle on the same seeded inputs, stage by stage with the oracle's stage inputs (teacher forcing).
+
+Tolerances (BASELINE.json north_star: activations within 1e-3 fp32, indices / keep masks exact):
+  * every stage fed with identical inputs: all activations within ACT_TOL = 1e-3 * (1 + |ref|);
+  * end to end: matched / keep indices exact, loss within 1e-3 relative; the refinement cascade re-samples the
+    feature maps at the previous stage's predicted positions, which amplifies fp32 rounding noise (1e-5 in a
+    position x (w-1) x feature slope), so chained-stage activations are held to: >= 99.5 % of the elements within
+    ACT_TOL and none beyond CASCADE_TOL = 5e-2 of the row scale."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import synth
+from oracle import phnet_cpu as O
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+ACT_TOL = 1e-3
+CASCADE_TOL = 5e-2
+
+
+def _gold(name):
+    return dict(np.load(os.path.join(GOLD, name)))
+
+
+def _build(g: O.Geometry):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from phnet_amd.config import make_cfg
+    from phnet_amd.libs.models.Router4OL import RouterOL
+    from phnet_amd.libs.utils.loss4OLV3 import Criterion4OL
+    cfg = make_cfg(img_h=g.img_h, img_w=g.img_w, arch=g.arch)
+    model = RouterOL(cfg, Criterion4OL(cfg))
+    model.load_state_dict(synth.make_state(g), strict=True)
+    for m in model.detNet.transformer_Dec.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+        if isinstance(m, torch.nn.MultiheadAttention):
+            m.dropout = 0.0
+    return model.cuda()
+
+
+def _close(a, b, tol=ACT_TOL, what=""):
+    a = torch.as_tensor(a).detach().cpu().double()
+    b = torch.as_tensor(b).detach().cpu().double()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = (a - b).abs()
+    bound = tol * (1.0 + b.abs())
+    bad = err > bound
+    assert not bool(bad.any()), (what, float(err.max()), int(bad.sum()), float(b.abs().max()))
+
+
+def _close_lines(a, b, what="", cascade=False):
+    """Lane tensors [...,6+S]: cls/start/theta/length columns element-wise; the S x-columns of a row all derive from
+    that row's (start, theta) through 1/tan(theta*pi), so they are judged against the row's own scale.
+    cascade=True: chained-stage criterion of the module docstring."""
+    a = torch.as_tensor(a).detach().cpu().double()
+    b = torch.as_tensor(b).detach().cpu().double()
+    head = (a[..., :6] - b[..., :6]).abs() / (1.0 + b[..., :6].abs())
+    xs = (a[..., 6:] - b[..., 6:]).abs() / (1.0 + b[..., 6:].abs().amax(dim=-1, keepdim=True))
+    err = torch.cat([head, xs], dim=-1)
+    if not cascade:
+        assert float(err.max()) <= ACT_TOL, (what, float(err.max()))
+    else:
+        frac = float((err <= ACT_TOL).double().mean())
+        assert frac >= 0.995 and float(err.max()) <= CASCADE_TOL, (what, frac, float(err.max()))
+
+
+def _record_heads(model):
+    rec = {"fir": [], "sec": [], "gate": [], "matched": [], "frame_loss": []}
+    det, crit = model.detNet, model.criterion
+    det_fwd, crit_fwd = det.forward, crit.forward
+
+    def det_hook(x, last_cuts=None):
+        o, cut, diff = det_fwd(x, last_cuts)
+        rec["fir"].append(torch.stack([p.detach()[0] for p in o["predictions_fir"]]).cpu())
+        rec["sec"].append(torch.stack([p.detach()[0] for p in o["predictions_sec"]]).cpu())
+        rec["gate"].append(torch.stack([d.detach()[0, :, 0] for d in diff]).cpu())
+        return o, cut, diff
+
+    def crit_hook(o, gt, diff=None):
+        m, l = crit_fwd(o, gt, diff)
+        rec["matched"].append([np.asarray(x, dtype=np.int64) for x in m])
+        rec["frame_loss"].append(float(l.detach()))
+        return m, l
+    det.forward, crit.forward = det_hook, crit_hook
+    return rec, lambda: (setattr(det, "forward", det_fwd), setattr(crit, "forward", crit_fwd))
+
+
+def _train_case(g, T, gold_file, grad_names_file):
+    gold = _gold(gold_file)
+    names = json.load(open(os.path.join(GOLD, grad_names_file)))
+    model = _build(g)
+    model.train()
+    rec, undo = _record_heads(model)
+    frames, lanes = synth.make_clip(g, T).cuda(), synth.make_targets(g, T).cuda()
+    loss = model({"frame": frames, "lanes": lanes})
+    loss.backward()
+    torch.cuda.synchronize()
+    undo()
+    # indices first: exact
+    for t in range(T):
+        for s in range(3):
+            assert rec["matched"][t][s].tolist() == [i for i in gold["train_matched"][t, s].tolist() if i >= 0], (t, s)
+    for t in range(T):
+        ga, gb = rec["gate"][t].double(), torch.as_tensor(gold["train_gate"][t]).double()
+        if t == 0:
+            _close(ga[0], gb[0], what="gate t=0 stage 0")
+        gerr = (ga - gb).abs()
+        assert float((gerr <= ACT_TOL).double().mean()) >= 0.995 and float(gerr.max()) <= CASCADE_TOL, (f"gate t={t}", float(gerr.max()))
+        if "train_fir" in gold:
+            _close_lines(rec["fir"][t][0], gold["train_fir"][t][0], what=f"fir t={t} stage 0", cascade=t > 0)
+            _close_lines(rec["sec"][t][0], gold["train_sec"][t][0], what=f"sec t={t} stage 0", cascade=t > 0)
+            _close_lines(rec["fir"][t][1:], gold["train_fir"][t][1:], what=f"fir t={t}", cascade=True)
+            _close_lines(rec["sec"][t][1:], gold["train_sec"][t][1:], what=f"sec t={t}", cascade=True)
+    _close(np.array(rec["frame_loss"]), gold["train_frame_loss"], what="frame loss")
+    assert abs(loss.item() - gold["train_loss"]) <= ACT_TOL * abs(gold["train_loss"])
+    bn = model.backbone.backbone.model.bn1
+    _close(bn.running_mean, gold["train_bn1_running_mean"], 1e-4, "bn1 running mean")
+    _close(bn.running_var, gold["train_bn1_running_var"], 1e-4, "bn1 running var")
+    params = dict(model.named_parameters())
+    worst = 0.0
+    for i, k in enumerate(names):
+        gr = params[k].grad
+        assert gr is not None, k
+        ref = float(gold["train_grad_norm"][i])
+        got = float(gr.double().norm())
+        rel = abs(got - ref) / (ref + 1e-6)
+        worst = max(worst, rel)
+        assert rel <= 5e-3 or abs(got - ref) <= 1e-5, (k, got, ref)
+        head = gr.flatten()[:4].double().cpu().numpy()
+        np.testing.assert_allclose(head, gold["train_grad_head"][i][:len(head)], rtol=2e-2,
+                                   atol=5e-3 * ref / max(1.0, gr.numel() ** 0.5) + 1e-6, err_msg=k)
+    return model, worst
+
+
+def _eval_case(g, T, gold_file):
+    gold = _gold(gold_file)
+    model = _build(g)
+    model.eval()
+    rec = {"lines": [], "keep_inds": [], "keep": []}
+    det = model.detNet
+    gl = det.get_lanes
+
+    def hook(output, *a, **k):
+        rec["lines"].append(output.detach()[0].cpu())
+        dec, ki, kp = gl(output, *a, **k)
+        rec["keep_inds"].append(ki.cpu().numpy())
+        rec["keep"].append(np.asarray(kp.cpu() if torch.is_tensor(kp) else kp, dtype=np.int64))
+        return dec, ki, kp
+    det.get_lanes = hook
+    with torch.no_grad():
+        res = model({"frame": synth.make_clip(g, T, seed=77).cuda(), "lanes": synth.make_targets(g, T).cuda()})
+    det.get_lanes = gl
+    for t in range(T):
+        _close_lines(rec["lines"][t], gold["eval_lines"][t], what=f"lines t={t}", cascade=True)
+        assert (rec["keep_inds"][t] == gold["eval_keep_inds"][t]).all(), t          # bit-exact keep mask
+        assert rec["keep"][t].tolist() == [i for i in gold["eval_keep"][t].tolist() if i >= 0], t
+        lanes = res["lane_lines"][t]
+        assert len(lanes) == int((gold["eval_lane_npts"][t] > 0).sum())
+        for j, lane in enumerate(lanes):
+            n = int(gold["eval_lane_npts"][t, j])
+            assert lane.points.shape == (n, 2)
+            np.testing.assert_allclose(lane.points, gold["eval_lane_pts"][t, j, :n], atol=ACT_TOL)
+
+
+def test_tiny_train_parity_vs_reference_goldens():
+    _train_case(O.Geometry(img_h=64, img_w=160, arch="resnet18"), 3, "tiny_r18_64x160.npz", "grad_names_resnet18.json")
+
+
+def test_tiny_eval_parity_vs_reference_goldens():
+    _eval_case(O.Geometry(img_h=64, img_w=160, arch="resnet18"), 4, "tiny_r18_64x160.npz")
+
+
+def test_tiny_fpn_maps_vs_oracle():
+    g = O.Geometry(img_h=64, img_w=160, arch="resnet18")
+    gold = _gold("tiny_r18_64x160.npz")
+    model = _build(g)
+    model.train()
+    with torch.no_grad():
+        feats = model.backbone(synth.make_clip(g, 3).cuda())
+    for j, f in enumerate(feats):
+        _close(f.permute(0, 3, 1, 2), gold[f"train_fpn{j}"], what=f"fpn{j}")
+
+
+def test_config1_single_frame_r18_eval():
+    g = O.Geometry(arch="resnet18")
+    gold = _gold("config1_r18_320x800.npz")
+    model = _build(g)
+    model.eval()
+    with torch.no_grad():
+        feats = model.backbone(synth.make_clip(g, 1).cuda())
+    for j, f in enumerate(feats):
+        f = f.permute(0, 3, 1, 2)
+        _close(f[..., ::4, ::5], gold[f"fpn{j}_strided"], what=f"fpn{j}")
+    _eval_case(g, 1, "config1_r18_320x800.npz")
+
+
+def test_config2_clip_r34_train_parity():
+    _train_case(O.Geometry(arch="resnet34"), 5, "config2_r34_320x800.npz", "grad_names_resnet34.json")
+
+
+def test_config2_clip_r34_eval_parity():
+    _eval_case(O.Geometry(arch="resnet34"), 5, "config2_r34_320x800.npz")
+
+
+@pytest.mark.parametrize("training", [True, False])
+def test_tiny_every_stage_teacher_forced_vs_oracle(training):
+    """Each (frame, stage) of the HIP head is fed exactly the inputs the CPU oracle fed its own stage; every output
+    must then agree within ACT_TOL (no cascade amplification)."""
+    from oracle import lane_nms as ON
+    g = O.Geometry(img_h=64, img_w=160, arch="resnet18")
+    T = 3
+    model = _build(g)
+    model.train(training)
+    sd = synth.make_state(g)
+    frames, lanes = synth.make_clip(g, T), synth.make_targets(g, T)
+    col = {}
+    with torch.no_grad():
+        O.clip_forward(sd, frames, lanes if training else None, g, training, nms_fn=ON.lane_nms, collect=col)
+        feats = model.backbone(frames.cuda())
+        for j in range(3):
+            _close(feats[j].permute(0, 3, 1, 2), col["fpn"][j], what=f"fpn{j}")
+        det = model.detNet
+        for t in range(T):
+            fo = col["frames"][t]
+            levels = [f[t:t + 1] for f in feats][::-1]
+            for s in range(3):
+                si = fo.stage_inputs[s]
+                mem = torch.cat(si["mem"], 0).unsqueeze(1).cuda() if si["mem"] else None
+                r = det.stage_forward(levels[s], s, si["priors"].cuda(), si["on_map"].cuda().contiguous(), si["pro"].cuda(), mem)
+                tag = f"t{t} s{s} "
+                _close(r["gate"], fo.gates[s], what=tag + "gate")
+                _close(r["local"], fo.locals_[s], what=tag + "dynamic head")
+                _close(r["attn"][:, 0], fo.attn_feats[s], what=tag + "attn feat")
+                _close_lines(r["pred_a"], fo.predictions_fir[s], what=tag + "branch A")
+                _close_lines(r["pred_b"], fo.predictions_sec[s], what=tag + "branch B")
