@@ -64,6 +64,8 @@ int phnet_conv2d_dgrad(const float* dy, const float* w, const float* addend, flo
                        int32_t stride, int32_t pad, void* workspace, uint64_t ws_bytes, void* stream);
 /* host-side query (no device work; bm/bn/splits are HOST pointers): tile and split-K factor the two calls above use. */
 int phnet_conv2d_plan(int64_t M, int32_t Co, int32_t K, uint64_t ws_bytes, int32_t* bm, int32_t* bn, int32_t* splits);
+/* tuning aid for benchmarks only (process-global): force tile/split-K of the next fwd/dgrad calls; bm=0 -> heuristic. */
+int phnet_tune_force_conv_tile(int32_t bm, int32_t bn, int32_t splits);
 uint64_t phnet_conv2d_wgrad_workspace(int32_t N, int32_t Hi, int32_t Wi, int32_t Ci, int32_t Co,
                                       int32_t R, int32_t S, int32_t stride, int32_t pad);
 int phnet_conv2d_wgrad(const float* dy, const float* x, float* dw,
@@ -85,6 +87,14 @@ int phnet_bn_bwd(const float* dy, const float* x, const float* y, const float* s
                  const float* save_invstd, const float* gamma, float* dx, float* dres,
                  float* dgamma, float* dbeta, float* partial, float* c1, float* c2,
                  int64_t M, int32_t C, int32_t relu, int32_t dres_accumulate, int32_t param_accumulate, void* stream);
+
+/* split form for SyncBatchNorm (trainOL.py:141): local sums[2][C] = (sum g*xhat, sum g) -> caller all-reduces -> apply. */
+int phnet_bn_bwd_reduce(const float* dy, const float* x, const float* y, const float* mean, const float* invstd,
+                        float* sums, float* partial, float* c1_scratch, float* c2_scratch,
+                        int64_t M, int32_t C, int32_t relu, void* stream);
+int phnet_bn_bwd_apply(const float* dy, const float* x, const float* y, const float* mean, const float* invstd,
+                       const float* gamma, const float* c1, const float* c2, float* dx, float* dres,
+                       int64_t M, int32_t C, int32_t relu, int32_t dres_accumulate, void* stream);
 
 /* ---- MaxPool2d(3,2,1): libs/models/resnet.py:217,297 ---- */
 int phnet_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* argmax, int32_t N, int32_t Hi, int32_t Wi, int32_t C, void* stream);

@@ -74,26 +74,59 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(
         rc[i].ix0 = ox * g.stride - g.pad;
     }
 
+    // ---- running (tap, channel) decomposition of this thread's k index: one division at start-up, then
+    // carry-propagating adds per K step (the per-step integer divisions made the loop VALU-bound) ----------
+    struct KPos { int c, r, q; };
+    auto kpos_init = [&](int k, int ci) {
+        KPos p;
+        const int rs = k / ci;
+        p.c = k - rs * ci;
+        p.r = rs / g.S;
+        p.q = rs - p.r * g.S;
+        return p;
+    };
+    auto kpos_advance = [&](KPos& p, int ci) {
+        p.c += BK;
+        while (p.c >= ci) {
+            p.c -= ci;
+            if (++p.q == g.S) { p.q = 0; ++p.r; }
+        }
+    };
+    KPos ka = kpos_init(k_begin + a_chunk * 4, g.Ci);
+    KPos kb[B_LOADS];
+    int b_kk[B_LOADS], b_ch[B_LOADS];
+    if (B_DGRAD) {
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i) {
+            const int idx = tid + THREADS * i;                     // BK rows x BN/4 chunks
+            b_kk[i] = idx / (BN / 4);
+            b_ch[i] = idx - b_kk[i] * (BN / 4);
+            kb[i] = kpos_init(k_begin + b_kk[i], g.Ci);
+        }
+    }
+
     f32x4 a_reg[A_LOADS], b_reg[B_LOADS];
+    // loads the K step that starts at kt; MUST be called with kt = k_begin, k_begin+BK, ... in order
     auto load_global = [&](int kt) {
         // A: 4 consecutive lanes fetch the 64 contiguous bytes (16 channels) of one pixel tap
         const int k0 = kt + a_chunk * 4;
         const bool kok = k0 < k_end;
-        const int rs = kok ? k0 / g.Ci : 0;
-        const int c = k0 - rs * g.Ci;
-        const int r = rs / g.S, q = rs - r * g.S;
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i) {
-            int ty = rc[i].iy0 + r, tx = rc[i].ix0 + q;
+            int ty = rc[i].iy0 + ka.r, tx = rc[i].ix0 + ka.q;
             bool ok = kok && rc[i].ok && ty >= 0 && tx >= 0;
-            if (g.in_dil > 1) {
+            if (g.in_dil == 2) {
+                ok = ok && !((ty | tx) & 1);
+                ty >>= 1; tx >>= 1;
+            } else if (g.in_dil > 2) {
                 ok = ok && (ty % g.in_dil == 0) && (tx % g.in_dil == 0);
                 ty /= g.in_dil; tx /= g.in_dil;
             }
             ok = ok && ty < g.Hi && tx < g.Wi;
-            a_reg[i] = ok ? *reinterpret_cast<const f32x4*>(X + ((size_t)(rc[i].base + ty * g.Wi + tx)) * g.Ci + c)
+            a_reg[i] = ok ? *reinterpret_cast<const f32x4*>(X + ((size_t)(rc[i].base + ty * g.Wi + tx)) * g.Ci + ka.c)
                           : f32x4{0.f, 0.f, 0.f, 0.f};
         }
+        kpos_advance(ka, g.Ci);
         if (!B_DGRAD) {
             // B rows = output channels, K contiguous in the OHWI weight
 #pragma unroll
@@ -107,16 +140,12 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(
             // here g.Ci is the dY channel count (= weight Co) and g.Co the weight Ci
 #pragma unroll
             for (int i = 0; i < B_LOADS; ++i) {
-                const int idx = tid + THREADS * i;             // BK rows x BN/4 chunks
-                const int kk = idx / (BN / 4), ch = idx - kk * (BN / 4);
-                const int k = kt + kk, n = n0 + ch * 4;
-                bool ok = k < k_end && n < g.Co;
-                const int rs2 = ok ? k / g.Ci : 0;
-                const int co = k - rs2 * g.Ci;
-                const int r2 = rs2 / g.S, q2 = rs2 - r2 * g.S;
+                const int k = kt + b_kk[i], n = n0 + b_ch[i] * 4;
+                const bool ok = k < k_end && n < g.Co;
                 b_reg[i] = ok ? *reinterpret_cast<const f32x4*>(
-                                    W + ((size_t)(co * g.R + (g.R - 1 - r2)) * g.S + (g.S - 1 - q2)) * g.Co + n)
+                                    W + ((size_t)(kb[i].c * g.R + (g.R - 1 - kb[i].r)) * g.S + (g.S - 1 - kb[i].q)) * g.Co + n)
                               : f32x4{0.f, 0.f, 0.f, 0.f};
+                kpos_advance(kb[i], g.Ci);
             }
         }
     };
@@ -132,11 +161,8 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(
                 *reinterpret_cast<f32x4*>(b + ((tid >> 2) + 64 * i) * LDK + a_chunk * 4) = b_reg[i];
         } else {
 #pragma unroll
-            for (int i = 0; i < B_LOADS; ++i) {
-                const int idx = tid + THREADS * i;
-                const int kk = idx / (BN / 4), ch = idx - kk * (BN / 4);
-                *reinterpret_cast<f32x4*>(b + kk * B_PITCH + ch * 4) = b_reg[i];
-            }
+            for (int i = 0; i < B_LOADS; ++i)
+                *reinterpret_cast<f32x4*>(b + b_kk[i] * B_PITCH + b_ch[i] * 4) = b_reg[i];
         }
     };
 
@@ -254,36 +280,51 @@ __global__ __launch_bounds__(THREADS) void conv_wgrad_kernel(
         b_q[i] = rs - b_r[i] * g.S;
     }
 
+    // running (image, row, col) decomposition of the pixel each B chunk reads: divisions once, then carries
+    int b_n[B_LOADS], b_oy[B_LOADS], b_ox[B_LOADS];
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i) {
+        const int pp = min(p_begin + b_kk[i], max(P - 1, 0));
+        b_n[i] = pp / (g.Ho * g.Wo);
+        const int rem = pp - b_n[i] * (g.Ho * g.Wo);
+        b_oy[i] = rem / g.Wo;
+        b_ox[i] = rem - b_oy[i] * g.Wo;
+    }
+    int a_kk[A_LOADS], a_ch[A_LOADS];
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) {
+        const int idx = tid + THREADS * i;
+        a_kk[i] = idx / (BM / 4);
+        a_ch[i] = (idx - a_kk[i] * (BM / 4)) * 4;
+    }
+
     f32x4 a_reg[A_LOADS], b_reg[B_LOADS];
+    // loads the K step that starts at pixel pt; MUST be called with pt = p_begin, p_begin+BK, ... in order
     auto load_global = [&](int pt) {
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i) {
-            const int idx = tid + THREADS * i;
-            const int kk = idx / (BM / 4), ch = (idx - kk * (BM / 4)) * 4;
-            const int p = pt + kk, co = m0 + ch;
+            const int p = pt + a_kk[i], co = m0 + a_ch[i];
             a_reg[i] = (p < p_end && co < g.Co) ? *reinterpret_cast<const f32x4*>(dY + (size_t)p * g.Co + co)
                                                 : f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
         for (int i = 0; i < B_LOADS; ++i) {
             const int p = pt + b_kk[i];
-            bool ok = b_ok[i] && p < p_end;
-            const int pp = ok ? p : 0;
-            const int n = pp / (g.Ho * g.Wo), rem = pp - n * (g.Ho * g.Wo);
-            const int oy = rem / g.Wo, ox = rem - oy * g.Wo;
-            const int iy = oy * g.stride - g.pad + b_r[i], ix = ox * g.stride - g.pad + b_q[i];
-            ok = ok && iy >= 0 && iy < g.Hi && ix >= 0 && ix < g.Wi;
-            b_reg[i] = ok ? *reinterpret_cast<const f32x4*>(X + ((size_t)(n * g.Hi + iy) * g.Wi + ix) * g.Ci + b_c[i])
+            const int iy = b_oy[i] * g.stride - g.pad + b_r[i], ix = b_ox[i] * g.stride - g.pad + b_q[i];
+            const bool ok = b_ok[i] && p < p_end && iy >= 0 && iy < g.Hi && ix >= 0 && ix < g.Wi;
+            b_reg[i] = ok ? *reinterpret_cast<const f32x4*>(X + ((size_t)(b_n[i] * g.Hi + iy) * g.Wi + ix) * g.Ci + b_c[i])
                           : f32x4{0.f, 0.f, 0.f, 0.f};
+            b_ox[i] += BK;
+            while (b_ox[i] >= g.Wo) {
+                b_ox[i] -= g.Wo;
+                if (++b_oy[i] == g.Ho) { b_oy[i] = 0; ++b_n[i]; }
+            }
         }
     };
     auto store_lds = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < A_LOADS; ++i) {
-            const int idx = tid + THREADS * i;
-            const int kk = idx / (BM / 4), ch = (idx - kk * (BM / 4)) * 4;
-            *reinterpret_cast<f32x4*>(As + buf * A_FLOATS + kk * A_PITCH + ch) = a_reg[i];
-        }
+        for (int i = 0; i < A_LOADS; ++i)
+            *reinterpret_cast<f32x4*>(As + buf * A_FLOATS + a_kk[i] * A_PITCH + a_ch[i]) = a_reg[i];
 #pragma unroll
         for (int i = 0; i < B_LOADS; ++i)
             *reinterpret_cast<f32x4*>(Bs + buf * B_FLOATS + b_kk[i] * B_PITCH + b_col[i]) = b_reg[i];
@@ -365,9 +406,19 @@ TileChoice pick_tile(long M, long N)
 
 struct ConvPlan { int bm, bn, splits; long tiles; };
 
+int g_force_bm = 0, g_force_bn = 0, g_force_splits = 0;      // tuning aid (phnet_tune_force_conv_tile)
+
 ConvPlan plan_conv(long M, int Co, int K, bool has_ws, size_t ws_bytes)
 {
-    const TileChoice t = pick_tile(M, Co);
+    TileChoice t = pick_tile(M, Co);
+    if (g_force_bm) {
+        t = {g_force_bm, g_force_bn};
+        ConvPlan f{t.bm, t.bn, 1, ceil_div64(M, t.bm) * ceil_div64(Co, t.bn)};
+        int splits = g_force_splits > 0 ? g_force_splits : 1;
+        while (splits > 1 && (!has_ws || (size_t)splits * M * Co * sizeof(float) > ws_bytes)) --splits;
+        f.splits = splits;
+        return f;
+    }
     ConvPlan p{t.bm, t.bn, 1, ceil_div64(M, t.bm) * ceil_div64(Co, t.bn)};
     // split K when the tile grid cannot fill the chip and K is long enough to amortise the reduce
     if (has_ws && p.tiles < 256) {
@@ -417,6 +468,15 @@ PHNET_API int phnet_conv2d_plan(int64_t M, int32_t Co, int32_t K, uint64_t ws_by
     if (M < 1 || Co < 1 || K < 1 || !bm || !bn || !splits) return PHNET_ERR_ARG;
     const ConvPlan p = plan_conv((long)M, Co, K, ws_bytes > 0, (size_t)ws_bytes);
     *bm = p.bm; *bn = p.bn; *splits = p.splits;
+    return PHNET_OK;
+}
+
+// Tuning aid (process-global, not thread-safe, never used by the product path): force the tile (64|128 each) and
+// split-K factor of the next phnet_conv2d_fwd/_dgrad calls; bm = 0 restores the built-in heuristic.
+PHNET_API int phnet_tune_force_conv_tile(int32_t bm, int32_t bn, int32_t splits)
+{
+    if (bm != 0 && !((bm == 64 || bm == 128) && (bn == 64 || bn == 128))) return PHNET_ERR_ARG;
+    g_force_bm = bm; g_force_bn = bn; g_force_splits = splits;
     return PHNET_OK;
 }
 

@@ -66,39 +66,54 @@ __global__ __launch_bounds__(NT) void channel_partials_kernel(
     }
 }
 
-__global__ void bn_fwd_finalize_kernel(const float* __restrict__ partial, int nblk, long M, int C, float eps,
-                                       float momentum, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                       float* __restrict__ running_mean, float* __restrict__ running_var,
-                                       float* __restrict__ save_mean, float* __restrict__ save_invstd,
-                                       float* __restrict__ scale, float* __restrict__ shift, int training)
+// one 64-lane wave per channel: lanes stride over the per-block partial sums (fp64), shuffle-reduce, lane 0 finishes
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(NT) void bn_fwd_finalize_kernel(
+    const float* __restrict__ partial, int nblk, long M, int C, float eps,
+    float momentum, const float* __restrict__ gamma, const float* __restrict__ beta,
+    float* __restrict__ running_mean, float* __restrict__ running_var,
+    float* __restrict__ save_mean, float* __restrict__ save_invstd,
+    float* __restrict__ scale, float* __restrict__ shift, int training)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (c >= C) return;
     float mean, invstd;
     if (training) {
         double s = 0.0, ss = 0.0;
-        for (int b = 0; b < nblk; ++b) {
+        for (int b = lane; b < nblk; b += 64) {
             s += (double)partial[(size_t)b * 2 * C + c];
             ss += (double)partial[(size_t)b * 2 * C + C + c];
         }
+        s = wave_sum_f64(s);
+        ss = wave_sum_f64(ss);
         const double mu = s / (double)M;
         double var = ss / (double)M - mu * mu;
         var = var < 0.0 ? 0.0 : var;
         mean = (float)mu;
         invstd = (float)(1.0 / sqrt(var + (double)eps));
-        if (running_mean) {
-            const double unbiased = M > 1 ? var * (double)M / (double)(M - 1) : var;
-            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
-            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+        if (lane == 0) {
+            if (running_mean) {
+                const double unbiased = M > 1 ? var * (double)M / (double)(M - 1) : var;
+                running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+                running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+            }
+            if (save_mean) { save_mean[c] = mean; save_invstd[c] = invstd; }
         }
-        if (save_mean) { save_mean[c] = mean; save_invstd[c] = invstd; }
     } else {
         mean = running_mean[c];
         invstd = 1.0f / sqrtf(running_var[c] + eps);
     }
-    const float sc = gamma[c] * invstd;
-    scale[c] = sc;
-    shift[c] = beta[c] - mean * sc;
+    if (lane == 0) {
+        const float sc = gamma[c] * invstd;
+        scale[c] = sc;
+        shift[c] = beta[c] - mean * sc;
+    }
 }
 
 // y = x*scale[c] + shift[c] (+ residual) (relu)
@@ -116,17 +131,21 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ 
     reinterpret_cast<f32x4*>(y)[i] = v;
 }
 
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, long M, int C,
-                                       float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                       float* __restrict__ c1, float* __restrict__ c2, int accumulate)
+__global__ __launch_bounds__(NT) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, long M, int C,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                             float* __restrict__ c1, float* __restrict__ c2, int accumulate)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (c >= C) return;
     double s = 0.0, sx = 0.0;
-    for (int b = 0; b < nblk; ++b) {
+    for (int b = lane; b < nblk; b += 64) {
         s += (double)partial[(size_t)b * 2 * C + c];
         sx += (double)partial[(size_t)b * 2 * C + C + c];
     }
+    s = wave_sum_f64(s);
+    sx = wave_sum_f64(sx);
+    if (lane != 0) return;
     if (accumulate) { dgamma[c] += (float)sx; dbeta[c] += (float)s; }
     else { dgamma[c] = (float)sx; dbeta[c] = (float)s; }
     c1[c] = (float)(s / (double)M);
@@ -331,7 +350,7 @@ PHNET_API int phnet_bn_fwd_stats(const float* x, int64_t M, int32_t C, float eps
                            x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
                            partial, (long)M, C, rpb, 0);
     } else if (!running_mean || !running_var) return PHNET_ERR_ARG;
-    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, partial, nblk, (long)M, C, eps, momentum,
+    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 3) / 4), dim3(NT), 0, st, partial, nblk, (long)M, C, eps, momentum,
                        gamma, beta, running_mean, running_var, save_mean, save_invstd, scale, shift, training);
     return phnet_launch_status();
 }
@@ -363,11 +382,42 @@ PHNET_API int phnet_bn_bwd(const float* dy, const float* x, const float* y, cons
     const int nblk = (int)stat_blocks(M, &rpb);
     hipLaunchKernelGGL(channel_partials_kernel<1>, dim3(nblk), dim3(NT), 2 * NT * sizeof(f32x4), st,
                        x, dy, y, save_mean, save_invstd, partial, (long)M, C, rpb, relu);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, partial, nblk, (long)M, C,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(NT), 0, st, partial, nblk, (long)M, C,
                        dgamma, dbeta, c1, c2, param_accumulate);
     const long total4 = M * C / 4;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)ceil_div64(total4, NT)), dim3(NT), 0, st,
                        dy, x, y, save_mean, save_invstd, gamma, c1, c2, dx, dres, total4, C, relu, dres_accumulate);
+    return phnet_launch_status();
+}
+
+// Split form of phnet_bn_bwd for cross-rank (SyncBatchNorm) training: step 1 = local per-channel sums
+// sums[0][C] = sum g*xhat, sums[1][C] = sum g  (g = dy masked by y>0 when relu; xhat uses the GLOBAL mean/invstd);
+// the caller all-reduces `sums` (and the element count) and calls step 2 with c1 = sum_g/M_global, c2 = sum_gx/M_global.
+PHNET_API int phnet_bn_bwd_reduce(const float* dy, const float* x, const float* y, const float* mean, const float* invstd,
+                                  float* sums, float* partial, float* c1_scratch, float* c2_scratch,
+                                  int64_t M, int32_t C, int32_t relu, void* stream)
+{
+    if (M < 1 || !channels_ok(C) || !dy || !x || !mean || !invstd || !sums || !partial || !c1_scratch || !c2_scratch || (relu && !y))
+        return PHNET_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    long rpb;
+    const int nblk = (int)stat_blocks(M, &rpb);
+    hipLaunchKernelGGL(channel_partials_kernel<1>, dim3(nblk), dim3(NT), 2 * NT * sizeof(f32x4), st,
+                       x, dy, y, mean, invstd, partial, (long)M, C, rpb, relu);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(NT), 0, st, partial, nblk, (long)M, C,
+                       sums, sums + C, c1_scratch, c2_scratch, 0);
+    return phnet_launch_status();
+}
+
+PHNET_API int phnet_bn_bwd_apply(const float* dy, const float* x, const float* y, const float* mean, const float* invstd,
+                                 const float* gamma, const float* c1, const float* c2, float* dx, float* dres,
+                                 int64_t M, int32_t C, int32_t relu, int32_t dres_accumulate, void* stream)
+{
+    if (M < 1 || !channels_ok(C) || !dy || !x || !mean || !invstd || !gamma || !c1 || !c2 || !dx || (relu && !y))
+        return PHNET_ERR_ARG;
+    const long total4 = M * C / 4;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)ceil_div64(total4, NT)), dim3(NT), 0, (hipStream_t)stream,
+                       dy, x, y, mean, invstd, gamma, c1, c2, dx, dres, total4, C, relu, dres_accumulate);
     return phnet_launch_status();
 }
 

@@ -246,6 +246,58 @@ def bn_bwd(dy, x, y, save_mean, save_invstd, gamma, relu: bool, dres: Optional[t
     return dx, dgamma, dbeta
 
 
+def bn_fwd_sync(x, gamma, beta, running_mean, running_var, eps: float, momentum: float, residual=None, relu: bool = True,
+                group=None):
+    """Training-mode BatchNorm whose statistics are merged across the ranks of `group` (SyncBatchNorm,
+    trainOL.py:141): local (mean, var) from the statistics kernel -> one fp64 all-reduce -> global scale/shift."""
+    from . import parallel
+    _req(x, name="x")
+    c = x.shape[-1]
+    m = x.numel() // c
+    dev = x.device
+    scale = torch.empty(c, dtype=torch.float32, device=dev)
+    shift = torch.empty(c, dtype=torch.float32, device=dev)
+    sm = torch.empty(c, dtype=torch.float32, device=dev)
+    si = torch.empty(c, dtype=torch.float32, device=dev)
+    part = _partials(m, c, dev)
+    check(lib().phnet_bn_fwd_stats(_ptr(x), m, c, eps, momentum, _ptr(gamma), _ptr(beta), None, None, _ptr(sm), _ptr(si),
+                                   _ptr(scale), _ptr(shift), _ptr(part), 1, _stream()), "phnet_bn_fwd_stats")
+    var_local = (1.0 / si.double() ** 2 - eps).clamp_min(0.0).float()
+    g_mean, g_var, total = parallel.merge_batch_statistics(sm, var_local, m, group)
+    g_invstd = torch.rsqrt(g_var + eps)
+    if running_mean is not None:
+        running_mean.mul_(1 - momentum).add_(g_mean, alpha=momentum)
+        running_var.mul_(1 - momentum).add_(g_var * (total / max(total - 1, 1)), alpha=momentum)
+    scale = gamma * g_invstd
+    shift = beta - g_mean * scale
+    y = torch.empty_like(x)
+    check(lib().phnet_bn_apply(_ptr(x), _ptr(scale.contiguous()), _ptr(shift.contiguous()), _ptr(residual), _ptr(y), m, c,
+                               int(relu), _stream()), "phnet_bn_apply")
+    return y, g_mean.contiguous(), g_invstd.contiguous(), total
+
+
+def bn_bwd_sync(dy, x, y, mean, invstd, gamma, relu: bool, total: int, dres: Optional[torch.Tensor] = None, group=None):
+    """SyncBatchNorm backward: local (sum g*xhat, sum g) -> all-reduce -> dx with the global means; dgamma/dbeta stay
+    local (DDP averages parameter gradients afterwards), as torch.nn.SyncBatchNorm does."""
+    from . import parallel
+    _req(dy, name="dy")
+    c = x.shape[-1]
+    m = x.numel() // c
+    dev = x.device
+    sums = torch.empty(2, c, dtype=torch.float32, device=dev)
+    scratch = torch.empty(2, c, dtype=torch.float32, device=dev)
+    part = _partials(m, c, dev)
+    check(lib().phnet_bn_bwd_reduce(_ptr(dy), _ptr(x), _ptr(y), _ptr(mean), _ptr(invstd), _ptr(sums), _ptr(part),
+                                    _ptr(scratch[0]), _ptr(scratch[1]), m, c, int(relu), _stream()), "phnet_bn_bwd_reduce")
+    dgamma, dbeta = sums[0].clone(), sums[1].clone()
+    g = parallel.allreduce_sum_(sums.double(), group)
+    c2, c1 = (g[0] / total).float().contiguous(), (g[1] / total).float().contiguous()
+    dx = torch.empty_like(x)
+    check(lib().phnet_bn_bwd_apply(_ptr(dy), _ptr(x), _ptr(y), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(c1), _ptr(c2),
+                                   _ptr(dx), _ptr(dres), m, c, int(relu), 0, _stream()), "phnet_bn_bwd_apply")
+    return dx, dgamma, dbeta
+
+
 def maxpool_fwd(x):
     _req(x, name="x")
     n, hi, wi, c = x.shape

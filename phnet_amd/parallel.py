@@ -1,0 +1,96 @@
+"""Data-parallel host logic: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box,
+"gloo" in the CPU tests).  The path shards by clip (reference: DistributedSampler + DDP + SyncBatchNorm,
+trainOL.py:34,83,141-146); the only data-path collectives are the gradient all-reduce (DDP buckets) and the
+SyncBatchNorm statistic exchange implemented here.
+
+Everything in this file works on tensors of either device, so the N>1 logic is testable with gloo on CPU.
+"""
+import os
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
+    """(rank, world, local_rank) from torchrun's env; initialises the default group when WORLD_SIZE > 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend=backend or ("nccl" if torch.cuda.is_available() else "gloo"), init_method="env://")
+    return rank, world, local_rank
+
+
+def shard_indices(n_units: int, rank: int, world: int, shuffle_seed: Optional[int] = None) -> List[int]:
+    """Clip indices of this rank: rank, rank+world, ... over a list padded by wrap-around to a multiple of `world`
+    (the partition torch's DistributedSampler produces, trainOL.py:83)."""
+    order = list(range(n_units))
+    if shuffle_seed is not None:
+        g = torch.Generator()
+        g.manual_seed(shuffle_seed)
+        order = torch.randperm(n_units, generator=g).tolist()
+    total = ((n_units + world - 1) // world) * world
+    pad = total - n_units
+    if pad:
+        order += (order * ((pad + n_units - 1) // max(n_units, 1) + 1))[:pad]
+    return order[rank:total:world]
+
+
+def active(group=None) -> bool:
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+
+
+def merge_batch_statistics(mean: torch.Tensor, var_biased: torch.Tensor, count: int, group=None):
+    """Combine per-rank (mean, biased variance, element count) of one BatchNorm layer into the statistics of the
+    union batch.  One all-reduce of a [3,C]-ish fp64 buffer: (count, count*mean, count*(var+mean^2))."""
+    c = mean.numel()
+    buf = torch.empty(2 * c + 1, dtype=torch.float64, device=mean.device)
+    buf[0] = float(count)
+    buf[1:1 + c] = mean.double() * count
+    buf[1 + c:] = (var_biased.double() + mean.double() ** 2) * count
+    if active(group):
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    total = buf[0]
+    g_mean = buf[1:1 + c] / total
+    g_var = (buf[1 + c:] / total - g_mean ** 2).clamp_min(0.0)
+    return g_mean.float(), g_var.float(), int(round(float(total)))
+
+
+def allreduce_sum_(t: torch.Tensor, group=None) -> torch.Tensor:
+    if active(group):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+def average_gradients_(params, bucket_bytes: int = 96 << 20, group=None) -> int:
+    """Bucketed gradient averaging for callers that do not use DDP: gradients are packed into flat fp32 buckets of
+    ~bucket_bytes (few large collectives: xGMI links are point-to-point, per-link bound), all-reduced asynchronously,
+    then scattered back.  Returns the number of collectives issued."""
+    if not active(group):
+        return 0
+    world = dist.get_world_size(group)
+    grads = [p.grad for p in params if p.grad is not None]
+    buckets, cur, size = [], [], 0
+    for g in grads:
+        cur.append(g)
+        size += g.numel() * 4
+        if size >= bucket_bytes:
+            buckets.append(cur)
+            cur, size = [], 0
+    if cur:
+        buckets.append(cur)
+    work = []
+    for b in buckets:
+        flat = torch.cat([g.reshape(-1) for g in b])
+        work.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True), flat, b))
+    for w, flat, b in work:
+        w.wait()
+        flat.div_(world)
+        off = 0
+        for g in b:
+            g.copy_(flat[off:off + g.numel()].view_as(g))
+            off += g.numel()
+    return len(buckets)

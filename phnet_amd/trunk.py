@@ -32,7 +32,7 @@ def _sync_bn(bn) -> bool:
 
 class _ConvBN:
     """Tape record of conv -> BN(+residual)(+ReLU)."""
-    __slots__ = ("conv", "bn", "stride", "pad", "x_in", "w", "c", "y", "sm", "si", "relu", "has_res")
+    __slots__ = ("conv", "bn", "stride", "pad", "x_in", "w", "c", "y", "sm", "si", "relu", "has_res", "sync_total")
 
 
 def _conv_bn(tape: list, x, conv: nn.Conv2d, bn, training: bool, relu: bool, residual=None, w_override=None):
@@ -42,10 +42,15 @@ def _conv_bn(tape: list, x, conv: nn.Conv2d, bn, training: bool, relu: bool, res
     rec.w = w_override if w_override is not None else ohwi(conv.weight)
     rec.x_in = x
     rec.c = K.conv2d_fwd(x, rec.w, None, rec.stride, rec.pad)
+    mom = bn.momentum if bn.momentum is not None else 0.1
+    rec.sync_total = 0
     if training and _sync_bn(bn):
-        raise NotImplementedError("SyncBatchNorm statistics exchange is implemented in phnet_amd.parallel (see DESIGN.md)")
-    rec.y, rec.sm, rec.si = K.bn_fwd(rec.c, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
-                                     training, bn.eps, bn.momentum if bn.momentum is not None else 0.1, residual, relu)
+        rec.y, rec.sm, rec.si, rec.sync_total = K.bn_fwd_sync(rec.c, bn.weight.detach(), bn.bias.detach(), bn.running_mean,
+                                                              bn.running_var, bn.eps, mom, residual, relu,
+                                                              getattr(bn, "process_group", None))
+    else:
+        rec.y, rec.sm, rec.si = K.bn_fwd(rec.c, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
+                                         training, bn.eps, mom, residual, relu)
     if training and bn.num_batches_tracked is not None:
         bn.num_batches_tracked += 1
     rec.relu, rec.has_res = relu, residual is not None
@@ -119,7 +124,11 @@ class EncoderFunction(torch.autograd.Function):
         pos = len(tape)
 
         def bn_back(rec, dy, dres=None, dres_acc=False):
-            dx, dg, db = K.bn_bwd(dy, rec.c, rec.y, rec.sm, rec.si, rec.bn.weight.detach(), rec.relu, dres, dres_acc)
+            if rec.sync_total:
+                dx, dg, db = K.bn_bwd_sync(dy, rec.c, rec.y, rec.sm, rec.si, rec.bn.weight.detach(), rec.relu,
+                                           rec.sync_total, dres, getattr(rec.bn, "process_group", None))
+            else:
+                dx, dg, db = K.bn_bwd(dy, rec.c, rec.y, rec.sm, rec.si, rec.bn.weight.detach(), rec.relu, dres, dres_acc)
             put(rec.bn.weight, dg)
             put(rec.bn.bias, db)
             return dx

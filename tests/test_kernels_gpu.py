@@ -230,3 +230,22 @@ def test_upsample_add_fwd_bwd(ops, H, W, h, w):
     close(out, ref.permute(0, 2, 3, 1), 1e-6)
     dc = ops.upsample_add_bwd_(nhwc(g.float()), torch.zeros(2, h, w, 64, device="cuda"))
     close(dc, coarse.grad.permute(0, 2, 3, 1), 1e-6)
+
+
+def test_syncbn_split_path_equals_fused_path_on_one_rank(ops):
+    """The SyncBatchNorm route (local sums -> all-reduce -> apply) with no process group must reproduce the fused route."""
+    torch.manual_seed(5)
+    x = torch.randn(3, 12, 14, 64, device="cuda") * 2 + 0.3
+    g, b = torch.rand(64, device="cuda") + 0.5, torch.randn(64, device="cuda")
+    rm1, rv1 = torch.zeros(64, device="cuda"), torch.ones(64, device="cuda")
+    rm2, rv2 = rm1.clone(), rv1.clone()
+    res = torch.randn_like(x)
+    y1, sm1, si1 = ops.bn_fwd(x, g, b, rm1, rv1, True, 1e-5, 0.1, res, True)
+    y2, sm2, si2, total = ops.bn_fwd_sync(x, g, b, rm2, rv2, 1e-5, 0.1, res, True)
+    assert total == x.numel() // 64
+    close(y2, y1, 1e-5); close(sm2, sm1, 1e-6); close(si2, si1, 1e-5); close(rm2, rm1, 1e-6); close(rv2, rv1, 1e-5)
+    dy = torch.randn_like(x)
+    d1 = torch.zeros_like(x); d2 = torch.zeros_like(x)
+    dx1, dg1, db1 = ops.bn_bwd(dy, x, y1, sm1, si1, g, True, d1)
+    dx2, dg2, db2 = ops.bn_bwd_sync(dy, x, y2, sm2, si2, g, True, total, d2)
+    close(dx2, dx1, 1e-5); close(dg2, dg1, 1e-5); close(db2, db1, 1e-5); close(d2, d1, 1e-7)

@@ -1,0 +1,57 @@
+"""GPU-box micro-benchmark of the implicit-GEMM kernel: tile / split-K sweep on the hot shapes."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+from phnet_amd import hip_ops as K
+from phnet_amd._lib import lib
+
+SHAPES = [  # name, N,Hi,Wi,Ci,Co,R,stride,pad
+    ("layer1 3x3", 5, 80, 200, 64, 64, 3, 1, 1),
+    ("layer2 3x3", 5, 40, 100, 128, 128, 3, 1, 1),
+    ("layer3 3x3", 5, 20, 50, 256, 256, 3, 1, 1),
+    ("layer4 3x3", 5, 10, 25, 512, 512, 3, 1, 1),
+    ("stem 7x7", 5, 320, 800, 4, 64, 7, 2, 3),
+    ("hyper 1024->8192", 240, 1, 1, 1024, 8192, 1, 1, 0),
+    ("hyper 4608->1024", 240, 1, 1, 4608, 1024, 1, 1, 0),
+    ("hyper 64->1024", 240, 1, 1, 64, 1024, 1, 1, 0),
+    ("gate 2304->576", 240, 1, 1, 2304, 576, 1, 1, 0),
+    ("out 2304->384", 240, 1, 1, 2304, 384, 1, 1, 0),
+    ("tower 64->64", 240, 1, 1, 64, 64, 1, 1, 0),
+    ("tower 128->128", 240, 1, 1, 128, 128, 1, 1, 0),
+]
+
+def timeit(fn, iters=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3  # us
+
+def main():
+    for name, N, Hi, Wi, Ci, Co, R, st, pad in SHAPES:
+        x = torch.randn(N, Hi, Wi, Ci, device="cuda"); w = torch.randn(Co, R, R, Ci, device="cuda") * 0.05
+        ho, wo = K.conv_out_hw(Hi, Wi, R, R, st, pad)
+        gy = torch.randn(N, ho, wo, Co, device="cuda")
+        fl = 2.0 * N * ho * wo * Co * R * R * Ci
+        res = []
+        for bm, bn in [(0, 0), (64, 64), (128, 64), (64, 128), (128, 128)]:
+            for sp in ([0] if bm == 0 else [1, 2, 4, 8, 16]):
+                M = N * ho * wo
+                if bm and sp > 1 and (M // bm + 1) * (Co // bn + 1) * sp > 4096: continue
+                lib().phnet_tune_force_conv_tile(bm, bn, sp)
+                try:
+                    tf = timeit(lambda: K.conv2d_fwd(x, w, None, st, pad))
+                    td = timeit(lambda: K.conv2d_dgrad(gy, w, (Hi, Wi), st, pad)) if Ci >= 64 else float("nan")
+                except RuntimeError as e:
+                    continue
+                res.append((bm, bn, sp, tf, td))
+        lib().phnet_tune_force_conv_tile(0, 0, 0)
+        tw = timeit(lambda: K.conv2d_wgrad(gy, x, w.shape, st, pad))
+        print(f"== {name}: {fl/1e9:.2f} GF; wgrad {tw:.1f} us = {fl/tw/1e6:.1f} TF/s")
+        for bm, bn, sp, tf, td in res:
+            print(f"   tile {bm:3d}x{bn:3d} splits {sp:2d}: fwd {tf:7.1f} us {fl/tf/1e6:6.1f} TF/s | dgrad {td:7.1f} us {fl/td/1e6:6.1f} TF/s")
+
+if __name__ == "__main__":
+    main()
