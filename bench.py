@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-clips", type=int, default=2)
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="do not capture the step in a hipGraph (always eager for N>1)")
     return ap.parse_args()
 
 
@@ -96,30 +97,50 @@ def main():
     model = RouterOL(cfg, Criterion4OL(cfg)).to(dev).train()
     # random-init cls/reg heads (std 1e-3) give ~0.5 scores everywhere, like the reference at initialisation
     net = model
-    if world > 1:
-        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], broadcast_buffers=False)
+    from phnet_amd import parallel
+    from phnet_amd.arena import GradArena
+    if world > 1:                                   # same initial weights on every rank (DDP's constructor broadcast)
+        for t_ in list(model.parameters()) + list(model.buffers()):
+            dist.broadcast(t_.data, src=0)
+    arena = GradArena(model.parameters())          # flat fp32 gradient buffer; HIP backward kernels accumulate into it
     decay = [p for p in model.parameters() if p.dim() > 1]
     no_decay = [p for p in model.parameters() if p.dim() <= 1]
+    use_graph = world == 1 and not args.eager
     opt = torch.optim.AdamW([{"params": decay, "weight_decay": 5e-4}, {"params": no_decay, "weight_decay": 0.0}],
-                            lr=5e-4, betas=(0.9, 0.999), fused=True)
+                            lr=5e-4, betas=(0.9, 0.999), fused=True, capturable=use_graph)
     T = args.frames
     lanes = make_targets(args.height, args.width, T).to(dev)
     clips = [make_clip(args.height, args.width, T, seed=3407 + rank + 17 * i).to(dev) for i in range(4)]
 
     def step(i):
-        opt.zero_grad(set_to_none=True)
+        arena.zero()
         loss = net({"frame": clips[i % len(clips)], "lanes": lanes}) / T
         loss.backward()
+        if world > 1:
+            parallel.allreduce_flat_(arena.flat, chunks=4)      # RCCL all-reduce (mean) of all gradients over xGMI
         opt.step()
         return loss
 
+    graphed = None
+    if use_graph:
+        from phnet_amd.graphed import GraphedTrainStep
+        try:
+            graphed = GraphedTrainStep(model, opt, clips[0], lanes, loss_divisor=T, warmup=2, arena=arena)
+            print("[bench] training step captured in a hipGraph", file=sys.stderr, flush=True)
+        except Exception as e:                                       # noqa: BLE001
+            print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr, flush=True)
+            graphed = None
+    eager_step = step
+    if graphed is not None:
+        def step(i):                                                 # noqa: F811
+            return graphed(clips[i % len(clips)])
     for i in range(args.warmup):
         step(i)
         torch.cuda.synchronize()
         print(f"[bench] rank {rank} warm-up step {i + 1}/{args.warmup} done", file=sys.stderr, flush=True)
     if world > 1:
         dist.barrier()
-    timer_on = not args.no_kernel_timer
+    timer_on = not args.no_kernel_timer and graphed is None
     if timer_on:
         hip_ops.TIMER = []
     torch.cuda.synchronize()
@@ -131,6 +152,16 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     records, hip_ops.TIMER = hip_ops.TIMER, None
+    timer_note = "HIP events around every launch of the kernel inside the timed region"
+    if graphed is not None and not args.no_kernel_timer:
+        # individual launches inside a graph replay cannot be bracketed by events: time the same kernels on the same
+        # shapes with one instrumented eager step right after the timed region
+        hip_ops.TIMER = []
+        eager_step(0)
+        torch.cuda.synchronize()
+        records, hip_ops.TIMER = hip_ops.TIMER, None
+        timer_note = "HIP events around every launch of the kernel in one instrumented eager step run right after the timed (graph-replay) region"
+    steps_timed = args.steps if graphed is None else 1
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -153,9 +184,9 @@ def main():
                     "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                     "launches": n, "avg_launch_us": round(sec / n * 1e6, 2), "gflop_per_launch": round(fl / n / 1e9, 3),
                     "mfma_dtype": "f32 (v_mfma_f32_32x32x2_f32)",
-                    "all_gemm_kernels": {k: {"launches": v[0], "TFLOP/s": round(v[1] / v[2] / 1e12, 2), "ms_per_step": round(v[2] / args.steps * 1e3, 3)}
+                    "all_gemm_kernels": {k: {"launches": v[0], "TFLOP/s": round(v[1] / v[2] / 1e12, 2), "ms_per_step": round(v[2] / steps_timed * 1e3, 3)}
                                          for k, v in sorted(agg.items())},
-                    "gemm_ms_per_step": round(total_gemm_s / args.steps * 1e3, 3)}
+                    "gemm_ms_per_step": round(total_gemm_s / steps_timed * 1e3, 3), "timing": timer_note}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args)
@@ -164,7 +195,8 @@ def main():
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": f"{T}-frame clip 3x{args.height}x{args.width}, {args.arch} + router + lane head, fwd+bwd+AdamW, "
                                       f"1 clip/GPU/step, random-init weights", "parallelism": f"dp{world}",
-                          "timed_region": "zero_grad + forward + loss + backward (+DDP all-reduce) + optimizer step"},
+                          "timed_region": "grad-arena memset + forward + loss + backward (+ flat RCCL all-reduce when N>1) + AdamW step",
+                          "launch": "hipGraph replay of the whole step" if graphed is not None else "eager"},
                "loss": round(float(loss.item()), 4), "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -121,6 +121,14 @@ int phnet_dwconv3x3(const float* x, const float* w, const float* bias, float* y,
 int phnet_dwconv3x3_wgrad(const float* dy, const float* x, float* dw, float* db,
                           int32_t N, int32_t C, int32_t P, int32_t accumulate, void* stream);
 
+/* ---- label assignment: replaces dynamic_assign.assign + scipy linear_sum_assignment on a .cpu() copy
+ * (libs/utils/dynamic_assign.py:128-190) with one device launch.  pred [N][6+S], tgt [L][6+S] (col 1 == 1 = valid),
+ * N <= 256, L <= 4.  rows_by_col [L] i64 (anchor matched to label j, -1 = none), rows_sorted [L] i64 (matched anchors
+ * ascending, -1 padded), n_valid (optional) i32, cost (optional) [N][L] f32 (the solver's matrix, +inf = invalid). ---- */
+int phnet_lane_assign(const float* pred, const float* tgt, int32_t N, int32_t L, int32_t S,
+                      float img_w, float img_h, int64_t* rows_by_col, int64_t* rows_sorted,
+                      int32_t* n_valid, float* cost, void* stream);
+
 /* ---- ReLU backward through the saved output (fused-ReLU epilogues of the linears) ---- */
 int phnet_relu_bwd(const float* dy, const float* y, float* dx, int64_t n, void* stream);
 

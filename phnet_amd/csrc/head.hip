@@ -69,6 +69,92 @@ __global__ __launch_bounds__(NT) void layernorm_bwd_dx_kernel(
     }
 }
 
+// ---- long rows (gate: L = C*P = 2304): one 256-thread workgroup per row, row kept in registers ----------------
+constexpr int LONG_MAX_PER_THREAD = 16;          // rows up to 4096 elements
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(NT) void layernorm_fwd_long_kernel(
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ res,
+    float* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd, int L, float eps, int relu)
+{
+    __shared__ float red[4];
+    const long row = blockIdx.x;
+    const float* xr = x + (size_t)row * L;
+    float v[LONG_MAX_PER_THREAD];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < LONG_MAX_PER_THREAD; ++k) {
+        const int i = threadIdx.x + k * NT;
+        v[k] = i < L ? xr[i] : 0.f;
+        s += v[k];
+    }
+    const float mu = block_sum(s, red) / (float)L;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < LONG_MAX_PER_THREAD; ++k) {
+        const int i = threadIdx.x + k * NT;
+        const float d = i < L ? v[k] - mu : 0.f;
+        q += d * d;
+    }
+    const float rs = 1.0f / sqrtf(block_sum(q, red) / (float)L + eps);
+    if (threadIdx.x == 0 && mean) { mean[row] = mu; rstd[row] = rs; }
+    const float* rr = res ? res + (size_t)row * L : nullptr;
+#pragma unroll
+    for (int k = 0; k < LONG_MAX_PER_THREAD; ++k) {
+        const int i = threadIdx.x + k * NT;
+        if (i < L) {
+            float o = (v[k] - mu) * rs * w[i] + b[i];
+            if (rr) o += rr[i];
+            if (relu) o = fmaxf(o, 0.f);
+            y[(size_t)row * L + i] = o;
+        }
+    }
+}
+
+__global__ __launch_bounds__(NT) void layernorm_bwd_dx_long_kernel(
+    const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ w,
+    const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ dx, float* __restrict__ dres,
+    int L, int relu)
+{
+    __shared__ float red[4];
+    const long row = blockIdx.x;
+    const size_t o = (size_t)row * L;
+    const float mu = mean[row], rs = rstd[row];
+    float g[LONG_MAX_PER_THREAD], xh[LONG_MAX_PER_THREAD];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < LONG_MAX_PER_THREAD; ++k) {
+        const int i = threadIdx.x + k * NT;
+        g[k] = 0.f; xh[k] = 0.f;
+        if (i < L) {
+            float gg = dy[o + i];
+            if (relu && !(y[o + i] > 0.f)) gg = 0.f;
+            g[k] = gg;
+            xh[k] = (x[o + i] - mu) * rs;
+            const float gw = gg * w[i];
+            s1 += gw;
+            s2 += gw * xh[k];
+        }
+    }
+    s1 = block_sum(s1, red) / (float)L;
+    s2 = block_sum(s2, red) / (float)L;
+#pragma unroll
+    for (int k = 0; k < LONG_MAX_PER_THREAD; ++k) {
+        const int i = threadIdx.x + k * NT;
+        if (i < L) {
+            dx[o + i] = rs * (g[k] * w[i] - s1 - xh[k] * s2);
+            if (dres) dres[o + i] = g[k];
+        }
+    }
+}
+
 // partial[slab][0][L] = sum_rows g*xhat, partial[slab][1][L] = sum_rows g   (rows of this slab)
 __global__ __launch_bounds__(NT) void layernorm_bwd_param_partial_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y,
@@ -199,8 +285,12 @@ PHNET_API int phnet_layernorm_fwd(const float* x, const float* w, const float* b
     if (rows < 0 || L < 1) return PHNET_ERR_ARG;
     if (rows == 0) return PHNET_OK;
     if (!x || !w || !b || !y || (!!mean != !!rstd)) return PHNET_ERR_ARG;
-    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((unsigned)ceil_div64(rows, NT / 64)), dim3(NT), 0, (hipStream_t)stream,
-                       x, w, b, res, y, mean, rstd, (long)rows, L, eps, relu);
+    if (L >= 1024 && L <= NT * LONG_MAX_PER_THREAD)
+        hipLaunchKernelGGL(layernorm_fwd_long_kernel, dim3((unsigned)rows), dim3(NT), 0, (hipStream_t)stream,
+                           x, w, b, res, y, mean, rstd, L, eps, relu);
+    else
+        hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((unsigned)ceil_div64(rows, NT / 64)), dim3(NT), 0, (hipStream_t)stream,
+                           x, w, b, res, y, mean, rstd, (long)rows, L, eps, relu);
     return phnet_launch_status();
 }
 
@@ -221,8 +311,12 @@ PHNET_API int phnet_layernorm_bwd(const float* dy, const float* x, const float* 
     if (rows == 0) return PHNET_OK;
     if (!dy || !x || !w || !mean || !rstd || !dx || (relu && !y)) return PHNET_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(layernorm_bwd_dx_kernel, dim3((unsigned)ceil_div64(rows, NT / 64)), dim3(NT), 0, st,
-                       dy, x, y, w, mean, rstd, dx, dres, (long)rows, L, relu);
+    if (L >= 1024 && L <= NT * LONG_MAX_PER_THREAD)
+        hipLaunchKernelGGL(layernorm_bwd_dx_long_kernel, dim3((unsigned)rows), dim3(NT), 0, st,
+                           dy, x, y, w, mean, rstd, dx, dres, L, relu);
+    else
+        hipLaunchKernelGGL(layernorm_bwd_dx_kernel, dim3((unsigned)ceil_div64(rows, NT / 64)), dim3(NT), 0, st,
+                           dy, x, y, w, mean, rstd, dx, dres, (long)rows, L, relu);
     if (dw && db) {
         const long slabs = max((long)1, min((long)128, (long)rows / 32));
         if (!workspace || (uint64_t)(slabs * 2 * L * sizeof(float)) > ws_bytes) return PHNET_ERR_WORKSPACE;

@@ -7,6 +7,7 @@ from typing import Optional
 import torch
 
 from . import hip_ops as K
+from .arena import direct_grad
 
 
 class _Linear(torch.autograd.Function):
@@ -23,6 +24,9 @@ class _Linear(torch.autograd.Function):
         y = K.linear_fwd(x2, wc, bc, relu)
         ctx.save_for_backward(x2, wc, y if relu else None)
         ctx.relu, ctx.has_b, ctx.xshape, ctx.n = relu, b is not None, x.shape, n
+        # arena-backed parameters: the backward kernels accumulate straight into .grad (phnet_amd/arena.py)
+        ctx.w_direct = direct_grad(w) if npad == 0 else None
+        ctx.b_direct = direct_grad(b) if (npad == 0 and b is not None) else None
         out = y if npad == 0 else y[:, :n]
         return out.reshape(*x.shape[:-1], n)
 
@@ -37,8 +41,17 @@ class _Linear(torch.autograd.Function):
         if ctx.relu:
             g = K.relu_bwd(g, y)
         dx = K.linear_dgrad(g, w).view(ctx.xshape) if ctx.needs_input_grad[0] else None
-        dw = K.linear_wgrad(g, x2)[:n] if ctx.needs_input_grad[1] else None
-        db = K.colsum(g)[:n] if (ctx.has_b and ctx.needs_input_grad[2]) else None
+        dw = db = None
+        if ctx.needs_input_grad[1]:
+            if ctx.w_direct is not None:
+                K.linear_wgrad(g, x2, dw=ctx.w_direct, accumulate=True)
+            else:
+                dw = K.linear_wgrad(g, x2)[:n]
+        if ctx.has_b and ctx.needs_input_grad[2]:
+            if ctx.b_direct is not None:
+                K.colsum(g, out=ctx.b_direct, accumulate=True)
+            else:
+                db = K.colsum(g)[:n]
         return dx, dw, db, None
 
 
@@ -57,11 +70,16 @@ class _LayerNorm(torch.autograd.Function):
         y, mean, rstd = K.layernorm_fwd(xc, wf, bf, eps, rc, relu)
         ctx.save_for_backward(xc, wf, y if relu else None, mean, rstd)
         ctx.relu, ctx.has_res, ctx.wshape = relu, res is not None, w.shape
+        ctx.w_direct, ctx.b_direct = direct_grad(w), direct_grad(b)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w, y, mean, rstd = ctx.saved_tensors
+        if ctx.w_direct is not None and ctx.b_direct is not None:
+            dx, dres, _, _ = K.layernorm_bwd(dy.contiguous(), x, y, w, mean, rstd, ctx.relu, ctx.has_res,
+                                             dw=ctx.w_direct.view(-1), db=ctx.b_direct.view(-1), accumulate=True)
+            return dx, None, None, dres, None, None
         dx, dres, dw, db = K.layernorm_bwd(dy.contiguous(), x, y, w, mean, rstd, ctx.relu, ctx.has_res)
         return dx, dw.view(ctx.wshape), db.view(ctx.wshape), dres, None, None
 
@@ -77,6 +95,7 @@ class _DwConv(torch.autograd.Function):
     def forward(ctx, x, w, b):
         xc, wc = x.contiguous(), w.contiguous()
         ctx.save_for_backward(xc, wc)
+        ctx.w_direct, ctx.b_direct = direct_grad(w), direct_grad(b)
         return K.dwconv3x3(xc, wc, b.contiguous())
 
     @staticmethod
@@ -84,6 +103,9 @@ class _DwConv(torch.autograd.Function):
         x, w = ctx.saved_tensors
         g = dy.contiguous()
         dx = K.dwconv3x3(g, w, None, flip=True) if ctx.needs_input_grad[0] else None
+        if ctx.w_direct is not None and ctx.b_direct is not None:
+            K.dwconv3x3_wgrad(g, x, dw=ctx.w_direct, db=ctx.b_direct, accumulate=True)
+            return dx, None, None
         dw, db = K.dwconv3x3_wgrad(g, x)
         return dx, dw.view_as(w), db
 
@@ -124,14 +146,18 @@ def bmm(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return torch.bmm(a, b)
 
 
-def attention_core(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, dropout_p: float = 0.0) -> torch.Tensor:
-    """q [L,E], k/v [M,E] -> softmax(q k^T / sqrt(d)) v, heads split along E."""
+def attention_core(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, dropout_p: float = 0.0,
+                   key_valid: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """q [L,E], k/v [M,E] -> softmax(q k^T / sqrt(d)) v, heads split along E; key_valid bool[M] masks padded keys."""
     L, e = q.shape
     d = e // heads
     qh = q.reshape(L, heads, d).transpose(0, 1) * (1.0 / (d ** 0.5))
     kh = k.reshape(-1, heads, d).transpose(0, 1)
     vh = v.reshape(-1, heads, d).transpose(0, 1)
-    att = torch.softmax(torch.bmm(qh, kh.transpose(1, 2)), dim=-1)
+    logits = torch.bmm(qh, kh.transpose(1, 2))
+    if key_valid is not None:
+        logits = logits.masked_fill(~key_valid[None, None, :], float("-inf"))
+    att = torch.softmax(logits, dim=-1)
     if dropout_p > 0.0:
         att = torch.nn.functional.dropout(att, dropout_p)
     return torch.bmm(att, vh).transpose(0, 1).reshape(L, e)

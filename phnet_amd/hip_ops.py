@@ -229,15 +229,16 @@ def bn_fwd(x, gamma, beta, running_mean, running_var, training: bool, eps: float
 
 
 def bn_bwd(dy, x, y, save_mean, save_invstd, gamma, relu: bool, dres: Optional[torch.Tensor] = None,
-           dres_accumulate: bool = False):
-    """Returns (dx, dgamma, dbeta); writes/accumulates the residual-branch gradient into dres when given."""
+           dres_accumulate: bool = False, dgamma: Optional[torch.Tensor] = None, dbeta: Optional[torch.Tensor] = None):
+    """Returns (dx, dgamma, dbeta); writes/accumulates the residual-branch gradient into dres when given.
+    dgamma/dbeta may be caller-provided destinations (overwritten)."""
     _req(dy, name="dy")
     c = x.shape[-1]
     m = x.numel() // c
     dev = x.device
     dx = torch.empty_like(x)
-    dgamma = torch.empty(c, dtype=torch.float32, device=dev)
-    dbeta = torch.empty(c, dtype=torch.float32, device=dev)
+    dgamma = torch.empty(c, dtype=torch.float32, device=dev) if dgamma is None else dgamma
+    dbeta = torch.empty(c, dtype=torch.float32, device=dev) if dbeta is None else dbeta
     c12 = torch.empty(2, c, dtype=torch.float32, device=dev)
     part = _partials(m, c, dev)
     check(lib().phnet_bn_bwd(_ptr(dy), _ptr(x), _ptr(y), _ptr(save_mean), _ptr(save_invstd), _ptr(gamma), _ptr(dx),
@@ -355,18 +356,19 @@ def layernorm_fwd(x, w, b, eps: float = 1e-5, res=None, relu: bool = False, save
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, y, w, mean, rstd, relu: bool, need_dres: bool = False):
-    """Returns (dx, dres or None, dw, db)."""
+def layernorm_bwd(dy, x, y, w, mean, rstd, relu: bool, need_dres: bool = False,
+                  dw: Optional[torch.Tensor] = None, db: Optional[torch.Tensor] = None, accumulate: bool = False):
+    """Returns (dx, dres or None, dw, db).  dw/db may be caller-provided [L] destinations (accumulated into when asked)."""
     _req(dy, name="dy")
     L = w.numel()
     rows = x.numel() // L
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if need_dres else None
-    dw = torch.empty_like(w)
-    db = torch.empty_like(w)
+    if dw is None:
+        dw, db, accumulate = torch.empty_like(w), torch.empty_like(w), False
     ws = workspace(lib().phnet_layernorm_bwd_workspace(rows, L), x.device, 2)
     check(lib().phnet_layernorm_bwd(_ptr(dy), _ptr(x), _ptr(y), _ptr(w), _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dres),
-                                    _ptr(dw), _ptr(db), rows, L, int(relu), 0, _ptr(ws), ws.numel(), _stream()),
+                                    _ptr(dw), _ptr(db), rows, L, int(relu), int(accumulate), _ptr(ws), ws.numel(), _stream()),
           "phnet_layernorm_bwd")
     return dx, dres, dw, db
 
@@ -380,12 +382,15 @@ def dwconv3x3(x, w, bias, flip: bool = False):
     return y
 
 
-def dwconv3x3_wgrad(dy, x):
+def dwconv3x3_wgrad(dy, x, dw: Optional[torch.Tensor] = None, db: Optional[torch.Tensor] = None, accumulate: bool = False):
     _req(dy, name="dy")
     n, c, p = x.shape
-    dw = torch.empty((n, 1, 3, 3), dtype=torch.float32, device=x.device)
-    db = torch.empty((n,), dtype=torch.float32, device=x.device)
-    check(lib().phnet_dwconv3x3_wgrad(_ptr(dy), _ptr(x), _ptr(dw), _ptr(db), n, c, p, 0, _stream()), "phnet_dwconv3x3_wgrad")
+    if dw is None:
+        dw = torch.empty((n, 1, 3, 3), dtype=torch.float32, device=x.device)
+        db = torch.empty((n,), dtype=torch.float32, device=x.device)
+        accumulate = False
+    check(lib().phnet_dwconv3x3_wgrad(_ptr(dy), _ptr(x), _ptr(dw), _ptr(db), n, c, p, int(accumulate), _stream()),
+          "phnet_dwconv3x3_wgrad")
     return dw, db
 
 
@@ -394,3 +399,17 @@ def relu_bwd(dy, y):
     dx = torch.empty_like(dy)
     check(lib().phnet_relu_bwd(_ptr(dy), _ptr(y), _ptr(dx), dy.numel(), _stream()), "phnet_relu_bwd")
     return dx
+
+
+def lane_assign(pred, tgt, img_w: int, img_h: int, want_cost: bool = False):
+    """pred [N,6+S], tgt [L,6+S] -> (rows_by_col [L] i64, rows_sorted [L] i64, n_valid [] i32[, cost [N,L]])."""
+    _req(pred, name="pred"); _req(tgt, name="tgt")
+    n, w = pred.shape
+    L = tgt.shape[0]
+    rows = torch.empty(L, dtype=torch.int64, device=pred.device)
+    srt = torch.empty(L, dtype=torch.int64, device=pred.device)
+    nv = torch.empty((), dtype=torch.int32, device=pred.device)
+    cost = torch.empty((n, L), dtype=torch.float32, device=pred.device) if want_cost else None
+    check(lib().phnet_lane_assign(_ptr(pred), _ptr(tgt), n, L, w - 6, float(img_w), float(img_h), _ptr(rows), _ptr(srt),
+                                  _ptr(nv), _ptr(cost), _stream()), "phnet_lane_assign")
+    return (rows, srt, nv, cost) if want_cost else (rows, srt, nv)

@@ -154,9 +154,12 @@ class DetNetV2(nn.Module):
         return self._branch(decode_feat_l, priors, False)
 
     def forward_second(self, last_cut, attn_feat, stage, priors):
-        """attn_feat [N,1,128]; last_cut [M,1,128] or None."""
+        """attn_feat [N,1,128]; last_cut: None, a [M,1,128] tensor, or (tokens [M,1,128], valid bool[M]) with fixed M."""
+        mask = None
+        if isinstance(last_cut, tuple):
+            last_cut, mask = last_cut
         if last_cut is not None and last_cut.shape[0] != 0:
-            feat = self.transformer_Dec(tgt=attn_feat, memory=last_cut)
+            feat = self.transformer_Dec(tgt=attn_feat, memory=last_cut, memory_key_valid=mask)
         else:
             feat = attn_feat
         return self._branch(feat.reshape(1, self.num_priors, -1), priors, True)
@@ -164,7 +167,7 @@ class DetNetV2(nn.Module):
     # ---- one refinement stage / one frame ---------------------------------------------------------------------
     def stage_forward(self, fmap, stage, priors, on_map, pro_feat, memory):
         """fmap [1,h,w,C] NHWC level of this stage; priors [1,N,6+S]; on_map [1,N,P]; pro_feat [1,N,C];
-        memory [M,1,2C] or None.  Returns dict(pred_a, lines_a, pred_b, lines_b, attn, gate, local)."""
+        memory None | [M,1,2C] | ([M,1,2C], valid bool[M]).  Returns dict(pred_a, lines_a, pred_b, lines_b, attn, gate, local)."""
         roi, roi_cp = PF.roi_pool(fmap, on_map, self.prior_feat_ys)                  # [1,N,P,C], [1,N,C,P]
         gate = self.router(roi_cp, stage)                                            # [1,N,1]
         local = self.DHead_series[stage](pro_feat, roi)                              # [1,N,C]
@@ -184,7 +187,9 @@ class DetNetV2(nn.Module):
         pro_feat = self.pro_embedding.weight.unsqueeze(0)
         out_a, out_b, attn_feats, gates = [], [], [], []
         for stage in range(self.refine_layers):
-            mem = torch.cat([fr[stage] for fr in last_cuts], dim=0) if len(last_cuts) else None
+            mem = None
+            if len(last_cuts):
+                mem = (torch.cat([fr[stage][0] for fr in last_cuts], dim=0), torch.cat([fr[stage][1] for fr in last_cuts], dim=0))
             r = self.stage_forward(levels[stage], stage, priors, on_map, pro_feat, mem)
             pro_feat = r["local"].detach()
             out_a.append(r["pred_a"]); out_b.append(r["pred_b"]); attn_feats.append(r["attn"]); gates.append(r["gate"])
@@ -283,24 +288,23 @@ class RouterOL(nn.Module):
                     last_cuts.pop(0)
         return total_loss if self.training else clip_outputs
 
-    @staticmethod
-    def _tokens(feat, mask):
-        return torch.cat([feat[mask], feat[~mask].mean(dim=0, keepdim=True)], dim=0)
+    def _tokens(self, feat, rows):
+        """feat [N,1,E]; rows i64[L] positive anchors ascending, -1 padded  ->  (tokens [L+1,1,E], valid bool[L+1]):
+        the positives in prior-index order, then the mean of all other anchors (Router4OL.py:563-584), fixed size."""
+        n = feat.shape[0]
+        valid = rows >= 0
+        vf = valid.to(feat.dtype)
+        safe = rows.clamp(min=0)
+        pos = feat[safe] * vf[:, None, None]
+        rest = (feat.sum(dim=0, keepdim=True) - pos.sum(dim=0, keepdim=True)) / (n - vf.sum())
+        return torch.cat([pos, rest], dim=0), torch.cat([valid, valid.new_ones(1)])
 
     def saveMemory(self, matched_indices, curr_cut):
-        memory = []
-        for matched, feat in zip(matched_indices, curr_cut):
-            mask = torch.zeros(self.detNet.num_priors, dtype=torch.bool, device=feat.device)
-            if len(matched):
-                mask[torch.as_tensor(matched, device=feat.device)] = True
-            memory.append(self._tokens(feat.detach(), mask))
-        return memory
+        return [self._tokens(feat.detach(), rows) for rows, feat in zip(matched_indices, curr_cut)]
 
     def saveMemory4Test(self, keep_inds, keep, curr_cut):
-        memory = []
-        for feat in curr_cut:
-            mask = torch.zeros(feat.shape[0], dtype=torch.bool, device=feat.device)
-            if len(keep):
-                mask[torch.where(keep_inds)[0][keep]] = True
-            memory.append(self._tokens(feat.detach(), mask))
-        return memory
+        rows = torch.full((self.detNet.cfg.max_lanes,), -1, dtype=torch.int64, device=curr_cut[0].device)
+        if len(keep):
+            idx = torch.sort(torch.where(keep_inds)[0][keep])[0]
+            rows[: idx.numel()] = idx
+        return [self._tokens(feat.detach(), rows) for feat in curr_cut]

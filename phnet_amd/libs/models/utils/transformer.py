@@ -10,8 +10,8 @@ import torch.nn.functional as F
 from phnet_amd import functional as PF
 
 
-def _attention(mha: nn.MultiheadAttention, q_in: torch.Tensor, kv_in: torch.Tensor, training: bool) -> torch.Tensor:
-    """q_in [L,E], kv_in [M,E] (batch 1, no masks) -> [L,E]."""
+def _attention(mha: nn.MultiheadAttention, q_in: torch.Tensor, kv_in: torch.Tensor, training: bool, key_valid=None) -> torch.Tensor:
+    """q_in [L,E], kv_in [M,E] (batch 1) -> [L,E]; key_valid bool[M] masks padded memory slots."""
     e, h = mha.embed_dim, mha.num_heads
     w, b = mha.in_proj_weight, mha.in_proj_bias
     q = PF.linear(q_in, w[:e], b[:e])
@@ -21,7 +21,7 @@ def _attention(mha: nn.MultiheadAttention, q_in: torch.Tensor, kv_in: torch.Tens
     else:
         k = PF.linear(kv_in, w[e:2 * e], b[e:2 * e])
         v = PF.linear(kv_in, w[2 * e:], b[2 * e:])
-    out = PF.attention_core(q, k, v, h, mha.dropout if training else 0.0)
+    out = PF.attention_core(q, k, v, h, mha.dropout if training else 0.0, key_valid)
     return PF.linear(out, mha.out_proj.weight, mha.out_proj.bias)
 
 
@@ -39,12 +39,12 @@ class TransformerDecoderLayer(nn.Module):
         self.dropout1, self.dropout2, self.dropout3 = nn.Dropout(dropout), nn.Dropout(dropout), nn.Dropout(dropout)
         self.normalize_before = normalize_before
 
-    def forward(self, tgt: torch.Tensor, memory: torch.Tensor) -> torch.Tensor:
-        """tgt [L,E], memory [M,E]."""
+    def forward(self, tgt: torch.Tensor, memory: torch.Tensor, memory_key_valid=None) -> torch.Tensor:
+        """tgt [L,E], memory [M,E], memory_key_valid bool[M] or None."""
         h = PF.layer_norm(tgt, self.norm1.weight, self.norm1.bias, eps=self.norm1.eps)
         tgt = tgt + self.dropout1(_attention(self.self_attn, h, h, self.training))
         h = PF.layer_norm(tgt, self.norm2.weight, self.norm2.bias, eps=self.norm2.eps)
-        tgt = tgt + self.dropout2(_attention(self.multihead_attn, h, memory, self.training))
+        tgt = tgt + self.dropout2(_attention(self.multihead_attn, h, memory, self.training, memory_key_valid))
         h = PF.layer_norm(tgt, self.norm3.weight, self.norm3.bias, eps=self.norm3.eps)
         h = self.dropout(F.gelu(PF.linear(h, self.linear1.weight, self.linear1.bias)))
         return tgt + self.dropout3(PF.linear(h, self.linear2.weight, self.linear2.bias))
@@ -58,12 +58,12 @@ class TransformerDecoder(nn.Module):
         self.norm = copy.deepcopy(norm)
         self.return_intermediate = return_intermediate
 
-    def forward(self, tgt: torch.Tensor, memory: torch.Tensor) -> torch.Tensor:
-        """tgt [L,1,E] or [L,E]; memory [M,1,E] or [M,E]; returns the same rank as tgt."""
+    def forward(self, tgt: torch.Tensor, memory: torch.Tensor, memory_key_valid=None) -> torch.Tensor:
+        """tgt [L,1,E] or [L,E]; memory [M,1,E] or [M,E]; memory_key_valid bool[M]; returns the same rank as tgt."""
         shape = tgt.shape
         x, mem = tgt.reshape(shape[0], shape[-1]), memory.reshape(memory.shape[0], memory.shape[-1])
         for layer in self.layers:
-            x = layer(x, mem)
+            x = layer(x, mem, memory_key_valid)
         if self.norm is not None:
             x = PF.layer_norm(x, self.norm.weight, self.norm.bias, eps=self.norm.eps)
         return x.reshape(shape)

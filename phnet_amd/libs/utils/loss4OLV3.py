@@ -2,17 +2,16 @@
 (`from libs.utils.loss4OLV3 import Criterion4OL`; reference: libs/utils/loss4OLV3.py:12-123 with
 dynamic_assign.py:128-190, focal_loss.py:78-136, dynamic_assignV2.py:55-98).
 
-Round-1 state: the cost matrix / focal / smooth-L1 / LaneIoU arithmetic runs as device tensor ops and the
-240 x <=4 assignment is solved on the host exactly as the reference does (scipy Hungarian on a .cpu() copy);
-the on-device assignment + fused loss kernels are the "next" rows of SURVEY.md 8(f)."""
+Sync-free and shape-static: the label assignment (cost matrix + exact matching) is one HIP launch
+(`phnet_lane_assign`), all label rows are carried with a validity mask instead of being filtered, and the matched
+anchors come back as a fixed-size device vector padded with -1.  Nothing in the criterion reads a device value on the
+host, so a whole training step can be captured in a hipGraph.  The focal / smooth-L1 / LaneIoU arithmetic is still
+expressed as device tensor ops."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
-from scipy.optimize import linear_sum_assignment
 
-
-def _masked(t, mask):
-    return t.masked_fill(mask, 0.0)
+from phnet_amd import hip_ops as K
 
 
 class Criterion4OL(nn.Module):
@@ -25,46 +24,23 @@ class Criterion4OL(nn.Module):
         self.focal_alpha, self.focal_gamma = (0.1, 0.9), 2.0
         # LaneIoULoss() is built with its class defaults, not cfg (dynamic_assignV2.py:56; loss4OLV3.py:28)
         self.liou_half_width, self.liou_img_h, self.liou_img_w = 7.5 / 768, 400, 960
+        self._consts = {}
 
-    # ---- label assignment --------------------------------------------------------------------------------
-    @torch.no_grad()
-    def assignment_cost(self, pred, tgt):
-        w, h = self.img_w, self.img_h
-        pxs, txs = pred[:, 6:] * (w - 1), tgt[:, 6:]
-        bad = (txs < 0) | (txs >= w)
-        d = _masked((txs[None] - pxs[:, None]).abs(), bad[None].expand(pxs.shape[0], -1, -1))
-        dist = d.sum(-1) / ((~bad).sum(1).float() + 1e-9)[None]
-        dist = 1 - dist / (dist.max() + 1e-4)
-        prob = pred[:, :2].sigmoid()
-        neg = -(1 - prob + 1e-12).log() * 0.75 * prob.pow(2)
-        posc = -(prob + 1e-12).log() * 0.25 * (1 - prob).pow(2)
-        lab = tgt[:, 1].long()
-        cls = posc[:, lab] - neg[:, lab]
-        scale = pred.new_tensor([h - 1.0, w - 1.0])
-        start = torch.cdist(pred[:, 2:4] * scale, tgt[:, 2:4] * scale, p=2)
-        start = 1 - start / (start.max() + 1e-4)
-        theta = torch.cdist(pred[:, 4:5], tgt[:, 4:5], p=1) * 180
-        theta = 1 - theta / (theta.max() + 1e-4)
-        cost = -(dist * start * theta) ** 2 * 3.0 + cls
-        lo_p, hi_p = (pxs - 15.0)[:, None], (pxs + 15.0)[:, None]
-        lo_t, hi_t = (txs - 15.0)[None], (txs + 15.0)[None]
-        ovr = _masked(torch.min(hi_p, hi_t) - torch.max(lo_p, lo_t), bad[None].expand(pxs.shape[0], -1, -1))
-        uni = _masked(torch.max(hi_p, hi_t) - torch.min(lo_p, lo_t), bad[None].expand(pxs.shape[0], -1, -1))
-        return cost - ovr.sum(-1) / (uni.sum(-1) + 1e-9)
-
-    @staticmethod
-    def solve(cost):
-        rows, cols = linear_sum_assignment(cost.detach().cpu().numpy(), maximize=False)
-        return torch.as_tensor(rows), torch.as_tensor(cols)
+    def _const(self, key, values, like):
+        k = (key, like.device)
+        if k not in self._consts:
+            self._consts[k] = torch.tensor(values, dtype=torch.float32, device=like.device)
+        return self._consts[k]
 
     # ---- loss terms ------------------------------------------------------------------------------------------
     def focal(self, logits, labels):
         p = F.softmax(logits, dim=1) + 1e-6
-        onehot = F.one_hot(labels, 2).to(logits.dtype) + 1e-6
-        focal = -logits.new_tensor(self.focal_alpha) * torch.pow(1.0 - p, self.focal_gamma) * torch.log(p)
+        onehot = torch.stack([1.0 - labels, labels], dim=1) + 1e-6
+        focal = -self._const("alpha", self.focal_alpha, logits) * torch.pow(1.0 - p, self.focal_gamma) * torch.log(p)
         return (onehot * focal).sum(dim=1)
 
-    def lane_iou(self, pred, tgt):
+    def lane_iou_rows(self, pred, tgt):
+        """1 - LaneIoU per row ([L])."""
         dy = self.liou_img_h / (pred.shape[1] - 1) * 2
         pd = (pred[:, 2:] - pred[:, :-2]).detach() * self.liou_img_w
         pw = self.liou_half_width * torch.sqrt(pd.pow(2) + dy ** 2) / dy
@@ -73,29 +49,33 @@ class Criterion4OL(nn.Module):
         td = torch.where(td.abs() > 1e4, torch.zeros_like(td), td)
         tw = self.liou_half_width * torch.sqrt(td.pow(2) + dy ** 2) / dy
         tw = torch.cat([tw[:, :1], tw, tw[:, -1:]], dim=1)
-        bad = (tgt < 0) | (tgt >= 1.0)
-        ovr = _masked(torch.min(pred + pw, tgt + tw) - torch.max(pred - pw, tgt - tw), bad)
-        uni = _masked(torch.max(pred + pw, tgt + tw) - torch.min(pred - pw, tgt - tw), bad)
-        return (1 - ovr.sum(-1) / (uni.sum(-1) + 1e-9)).mean()
+        ok = ~((tgt < 0) | (tgt >= 1.0))
+        ovr = (torch.min(pred + pw, tgt + tw) - torch.max(pred - pw, tgt - tw)) * ok
+        uni = (torch.max(pred + pw, tgt + tw) - torch.min(pred - pw, tgt - tw)) * ok
+        return 1 - ovr.sum(-1) / (uni.sum(-1) + 1e-9)
 
     def line_loss_diff(self, predictions_lists, targets):
+        """One branch, all stages.  Returns (matched [stages] x i64[L] ascending / -1 padded, cls[N], reg, iou)."""
         cls_sum, reg_sum, iou_sum, matched = 0.0, 0.0, 0.0, []
-        scale = targets.new_tensor([self.n_strips, self.img_w - 1.0, 180.0, self.n_strips])
+        scale = self._const("scale", [self.n_strips, self.img_w - 1.0, 180.0, self.n_strips], targets)
         for preds in predictions_lists:
-            for pred, target in zip(preds, targets):
-                tgt = target[target[:, 1] == 1]
-                labels = torch.zeros(pred.shape[0], dtype=torch.long, device=pred.device)
-                if tgt.shape[0] == 0:
-                    cls_sum = cls_sum + self.focal(pred[:, :2], labels)
-                    matched.append([])
-                    continue
-                rows, cols = self.solve(self.assignment_cost(pred.detach(), tgt))
-                matched.append(rows)
-                rows_d, cols_d = rows.to(pred.device), cols.to(pred.device)
-                labels[rows_d] = 1
+            for pred, tgt in zip(preds, targets):
+                pred_c = pred.contiguous()
+                rows, rows_sorted, _ = K.lane_assign(pred_c.detach(), tgt.contiguous(), self.img_w, self.img_h)
+                matched.append(rows_sorted)
+                valid = (rows >= 0)
+                vf = valid.to(pred.dtype)
+                m = vf.sum()
+                safe = rows.clamp(min=0)
+                labels = torch.zeros(pred.shape[0], dtype=pred.dtype, device=pred.device).index_put_((safe,), vf, accumulate=True)
                 cls_sum = cls_sum + self.focal(pred[:, :2], labels)
-                reg_sum = reg_sum + F.smooth_l1_loss(pred[rows_d, 2:6] * scale, tgt[cols_d, 2:6] * scale, reduction="none").mean()
-                iou_sum = iou_sum + self.lane_iou(pred[rows_d, 6:] * (self.img_w - 1) / self.img_w, tgt[cols_d, 6:] / self.img_w)
+                sel = pred[safe]                                                     # [L, 6+S]
+                # invalid label rows hold -1e5 everywhere: neutralise them BEFORE the arithmetic so no inf/nan appears
+                tsel = torch.where(valid[:, None], tgt, sel.detach())
+                reg = F.smooth_l1_loss(sel[:, 2:6] * scale, tsel[:, 2:6] * scale, reduction="none")
+                reg_sum = reg_sum + (reg * vf[:, None]).sum() / (m.clamp(min=1.0) * 4)
+                liou = self.lane_iou_rows(sel[:, 6:] * (self.img_w - 1) / self.img_w, tsel[:, 6:] / self.img_w)
+                iou_sum = iou_sum + (liou * vf).sum() / m.clamp(min=1.0)
         k = len(targets) * self.refine_layers
         return matched, cls_sum / k, reg_sum / k, iou_sum / k
 
@@ -111,4 +91,6 @@ class Criterion4OL(nn.Module):
         return matched_b, total
 
     def forward(self, output, gt_lane, diff=None):
+        """-> (matched anchors of branch B per stage: i64[L] ascending, padded with -1; scalar loss).
+        The reference returns variable-length index tensors; `matched[s][matched[s] >= 0]` recovers them."""
         return self.loss4OneStep(output, {"lane_line": gt_lane}, diff)

@@ -94,3 +94,19 @@ def average_gradients_(params, bucket_bytes: int = 96 << 20, group=None) -> int:
             g.copy_(flat[off:off + g.numel()].view_as(g))
             off += g.numel()
     return len(buckets)
+
+
+def allreduce_flat_(flat: torch.Tensor, chunks: int = 4, group=None) -> int:
+    """Average a flat gradient arena across ranks with `chunks` large asynchronous all-reduces (fewer, larger
+    collectives: xGMI is point-to-point, ring steps are per-link bound).  Returns the number of collectives."""
+    if not active(group):
+        return 0
+    world = dist.get_world_size(group)
+    n = flat.numel()
+    step = (n + chunks - 1) // chunks
+    work = [dist.all_reduce(flat[i:min(n, i + step)], op=dist.ReduceOp.SUM, group=group, async_op=True)
+            for i in range(0, n, step)]
+    for w in work:
+        w.wait()
+    flat.div_(world)
+    return len(work)

@@ -15,6 +15,7 @@ import torch.distributed as dist
 import torch.nn as nn
 
 from . import hip_ops as K
+from .arena import direct_grad
 
 
 def ohwi(w: torch.Tensor) -> torch.Tensor:
@@ -103,21 +104,39 @@ class EncoderFunction(torch.autograd.Function):
         def put(p, g):
             grads[ctx.index[id(p)]] = g
 
+        def dest_ohwi(p):
+            d = direct_grad(p)                    # arena view with the parameter's channels_last strides
+            return None if d is None else d.permute(0, 2, 3, 1)
+
+        def conv_wgrad_into(p, dy, x, wshape, stride, pad):
+            d = dest_ohwi(p)
+            if d is not None and d.is_contiguous():
+                K.conv2d_wgrad(dy, x, wshape, stride, pad, dw=d, accumulate=True)
+            else:
+                put(p, oihw_grad(K.conv2d_wgrad(dy, x, wshape, stride, pad)))
+
+        def bias_grad_into(p, dy):
+            d = direct_grad(p)
+            if d is not None:
+                K.colsum(dy.view(-1, dy.shape[-1]), out=d, accumulate=True)
+            else:
+                put(p, K.colsum(dy.view(-1, dy.shape[-1])))
+
         # ---- FPN ------------------------------------------------------------------------------------------
         douts = [d.contiguous() for d in (d3, d4, d5)]
         dl = []
         for i in range(3):
             m = neck.fpn_convs[i].conv
-            put(m.weight, oihw_grad(K.conv2d_wgrad(douts[i], ctx.lats[i], ctx.out_w[i].shape, 1, 1)))
-            put(m.bias, K.colsum(douts[i].view(-1, douts[i].shape[-1])))
+            conv_wgrad_into(m.weight, douts[i], ctx.lats[i], ctx.out_w[i].shape, 1, 1)
+            bias_grad_into(m.bias, douts[i])
             dl.append(K.conv2d_dgrad(douts[i], ctx.out_w[i], tuple(ctx.lats[i].shape[1:3]), 1, 1))
         for i in (1, 2):
             K.upsample_add_bwd_(dl[i - 1], dl[i])
         dstage = []
         for i in range(3):
             m = neck.lateral_convs[i].conv
-            put(m.weight, oihw_grad(K.conv2d_wgrad(dl[i], ctx.feats[i], ctx.lat_w[i].shape, 1, 0)))
-            put(m.bias, K.colsum(dl[i].view(-1, dl[i].shape[-1])))
+            conv_wgrad_into(m.weight, dl[i], ctx.feats[i], ctx.lat_w[i].shape, 1, 0)
+            bias_grad_into(m.bias, dl[i])
             dstage.append(K.conv2d_dgrad(dl[i], ctx.lat_w[i], tuple(ctx.feats[i].shape[1:3]), 1, 0))
         # ---- trunk, last block first ----------------------------------------------------------------------
         tape = ctx.tape
@@ -128,16 +147,23 @@ class EncoderFunction(torch.autograd.Function):
                 dx, dg, db = K.bn_bwd_sync(dy, rec.c, rec.y, rec.sm, rec.si, rec.bn.weight.detach(), rec.relu,
                                            rec.sync_total, dres, getattr(rec.bn, "process_group", None))
             else:
+                dgd, dbd = direct_grad(rec.bn.weight), direct_grad(rec.bn.bias)
+                if dgd is not None and dbd is not None:          # each BN is used once per step: plain overwrite
+                    dx, _, _ = K.bn_bwd(dy, rec.c, rec.y, rec.sm, rec.si, rec.bn.weight.detach(), rec.relu, dres, dres_acc,
+                                        dgamma=dgd, dbeta=dbd)
+                    return dx
                 dx, dg, db = K.bn_bwd(dy, rec.c, rec.y, rec.sm, rec.si, rec.bn.weight.detach(), rec.relu, dres, dres_acc)
             put(rec.bn.weight, dg)
             put(rec.bn.bias, db)
             return dx
 
         def conv_back(rec, dc, need_dx=True, addend=None):
-            dw = K.conv2d_wgrad(dc, rec.x_in, rec.w.shape, rec.stride, rec.pad)
             if rec.conv is model.conv1:
+                dw = K.conv2d_wgrad(dc, rec.x_in, rec.w.shape, rec.stride, rec.pad)
                 dw = K.pad_channels(dw.view(-1, 4), 3).view(dw.shape[0], 7, 7, 3)
-            put(rec.conv.weight, oihw_grad(dw))
+                put(rec.conv.weight, oihw_grad(dw))
+            else:
+                conv_wgrad_into(rec.conv.weight, dc, rec.x_in, rec.w.shape, rec.stride, rec.pad)
             if not need_dx:
                 return None
             return K.conv2d_dgrad(dc, rec.w, tuple(rec.x_in.shape[1:3]), rec.stride, rec.pad, addend)

@@ -249,3 +249,78 @@ def test_syncbn_split_path_equals_fused_path_on_one_rank(ops):
     dx1, dg1, db1 = ops.bn_bwd(dy, x, y1, sm1, si1, g, True, d1)
     dx2, dg2, db2 = ops.bn_bwd_sync(dy, x, y2, sm2, si2, g, True, total, d2)
     close(dx2, dx1, 1e-5); close(dg2, dg1, 1e-5); close(db2, db1, 1e-5); close(d2, d1, 1e-7)
+
+
+@pytest.mark.parametrize("n_valid,seed", [(3, 0), (4, 1), (1, 2), (0, 3), (2, 4)])
+def test_lane_assign_matches_scipy_on_oracle_cost(ops, n_valid, seed):
+    """Device-side cost matrix + exact matching vs the oracle's cost (dynamic_assign.py:128-185) + scipy Hungarian."""
+    from oracle import phnet_cpu as O
+    from tests import synth
+    g = O.Geometry()
+    r = np.random.default_rng(seed)
+    tgt = synth.make_targets(g, 1, n_lanes=4)[0]
+    order = r.permutation(4)
+    for j in order[n_valid:]:
+        tgt[j] = -1e5; tgt[j, 0] = 1; tgt[j, 1] = 0                         # invalid rows anywhere in the label block
+    pri, _ = O.priors_from_embeddings(O.initial_anchor_embeddings(g), g)
+    pred = pri.clone()
+    pred[:, :2] = torch.from_numpy(r.normal(0, 1, (240, 2)).astype(np.float32))
+    pred[:, 2:5] += torch.from_numpy(r.normal(0, 0.02, (240, 3)).astype(np.float32))
+    pred[:, 5] = 0.6
+    pred[:, 6:] += torch.from_numpy(r.normal(0, 0.01, (240, 36)).astype(np.float32))
+    rows, srt, nv, cost = ops.lane_assign(dev(pred), dev(tgt), g.img_w, g.img_h, want_cost=True)
+    assert int(nv) == n_valid
+    vmask = tgt[:, 1] == 1
+    if n_valid == 0:
+        assert rows.cpu().tolist() == [-1] * 4 and srt.cpu().tolist() == [-1] * 4
+        return
+    ref_cost = O.assignment_cost(pred, tgt[vmask], g)
+    close(cost.cpu()[:, vmask], ref_cost, 1e-4)
+    assert torch.isinf(cost.cpu()[:, ~vmask]).all()
+    rr, cc = O.hungarian(ref_cost)
+    want = [-1] * 4
+    cols = torch.where(vmask)[0]
+    for a, b in zip(rr.tolist(), cc.tolist()):
+        want[int(cols[b])] = a
+    assert rows.cpu().tolist() == want
+    assert srt.cpu().tolist() == sorted([w for w in want if w >= 0]) + [-1] * (4 - n_valid)
+
+
+@pytest.mark.parametrize("rows,L,relu,res", [(240, 2304, True, True), (240, 2304, False, False), (8640, 128, True, False),
+                                             (8640, 64, True, False), (240, 64, False, False), (240, 128, False, False), (7, 1000, True, True)])
+def test_layernorm_fwd_bwd(ops, rows, L, relu, res):
+    torch.manual_seed(rows + L)
+    x = (torch.randn(rows, L, dtype=torch.float64) * 1.5 + 0.2).requires_grad_(True)
+    w = (torch.rand(L, dtype=torch.float64) + 0.5).requires_grad_(True)
+    b = torch.randn(L, dtype=torch.float64, requires_grad=True)
+    r = torch.randn(rows, L, dtype=torch.float64, requires_grad=True) if res else None
+    y = F.layer_norm(x, [L], w, b, 1e-5)
+    if res:
+        y = y + r
+    if relu:
+        y = F.relu(y)
+    g = torch.randn_like(y)
+    y.backward(g)
+    yd, mean, rstd = ops.layernorm_fwd(dev(x.detach().float()), dev(w.detach().float()), dev(b.detach().float()), 1e-5,
+                                       dev(r.detach().float()) if res else None, relu)
+    close(yd, y, 1e-5)
+    dx, dres, dw, db = ops.layernorm_bwd(dev(g.float()), dev(x.detach().float()), yd, dev(w.detach().float()), mean, rstd, relu, res)
+    close(dx, x.grad, 2e-5); close(dw, w.grad, 2e-5); close(db, b.grad, 2e-5)
+    if res:
+        close(dres, r.grad, 1e-6)
+
+
+def test_dwconv3x3_fwd_bwd(ops):
+    torch.manual_seed(9)
+    N, C, P = 240, 64, 36
+    x = torch.randn(1, N, C, P, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(N, 1, 3, 3, dtype=torch.float64, requires_grad=True)
+    b = torch.randn(N, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(x, w, b, padding=1, groups=N)
+    g = torch.randn_like(y)
+    y.backward(g)
+    xd, wd = dev(x.detach().float()[0]), dev(w.detach().float())
+    close(ops.dwconv3x3(xd, wd, dev(b.detach().float())), y[0], 1e-5)
+    close(ops.dwconv3x3(dev(g.float()[0]), wd, None, flip=True), x.grad[0], 1e-5)
+    dw, db = ops.dwconv3x3_wgrad(dev(g.float()[0]), xd)
+    close(dw, w.grad, 2e-5); close(db, b.grad, 2e-5)
