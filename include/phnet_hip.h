@@ -129,6 +129,19 @@ int phnet_lane_assign(const float* pred, const float* tgt, int32_t N, int32_t L,
                       float img_w, float img_h, int64_t* rows_by_col, int64_t* rows_sorted,
                       int32_t* n_valid, float* cost, void* stream);
 
+/* ---- fused per-frame criterion: replaces Criterion4OL.loss4OneStep (libs/utils/loss4OLV3.py:34-82,100-123: assignment,
+ * focal, smooth-L1, LaneIoU, gate-weighted combination) AND its autograd backward with two launches.
+ * pred / gate / dpred are HOST arrays of device pointers: pred[6] = branch A stages 0..2 then branch B stages 0..2,
+ * each [N][6+S]; gate[3] each [N]; dpred[6] each [N][6+S].  tgt [L][6+S], L <= 4, N <= 256.
+ * Outputs: loss [1]; dpred, dgate [3][N] = d loss / d input for unit upstream gradient; rows_by_col / rows_sorted
+ * [6][L] int64 matched anchors (-1 padded).  Scratch: focal [6][N], scalars [12]. ---- */
+int phnet_frame_loss(const float* const* pred, const float* const* gate, const float* tgt,
+                     int32_t N, int32_t L, int32_t S, float img_w, float img_h,
+                     float cls_w, float reg_w, float iou_w,
+                     float liou_half_width, float liou_img_h, float liou_img_w,
+                     float* loss, float* const* dpred, float* dgate,
+                     int64_t* rows_by_col, int64_t* rows_sorted, float* focal, float* scalars, void* stream);
+
 /* ---- ReLU backward through the saved output (fused-ReLU epilogues of the linears) ---- */
 int phnet_relu_bwd(const float* dy, const float* y, float* dx, int64_t n, void* stream);
 

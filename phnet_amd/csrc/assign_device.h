@@ -1,0 +1,178 @@
+// Device-side body of the label assignment (see assign.hip): one 256-thread workgroup, callable from other kernels.
+#pragma once
+#include "common.h"
+
+namespace phassign {
+
+constexpr int NT = 256;
+constexpr int MAXL = 4;
+
+__device__ __forceinline__ float block_max(float v, float* red) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+__device__ __forceinline__ void lane_assign_block(
+    const float* __restrict__ pred, const float* __restrict__ tgt, int N, int L, int S, float img_w, float img_h,
+    int64_t* __restrict__ rows_by_col, int64_t* __restrict__ rows_sorted, int32_t* __restrict__ n_valid_out,
+    float* __restrict__ cost_out, float* cost /* LDS [N][MAXL] */)
+{
+    __shared__ float t_x[MAXL][256];                 // target xs (S <= 250)
+    __shared__ float t_len[MAXL], red[4];
+    __shared__ int t_valid[MAXL], top_rows[MAXL][MAXL], best_combo;
+    __shared__ float combo_cost[NT];
+    const int tid = threadIdx.x;
+    const int W = 6 + S;
+
+    if (tid < MAXL) {
+        t_valid[tid] = (tid < L) && (tgt[tid * W + 1] == 1.0f);
+        t_len[tid] = 0.f;
+    }
+    for (int i = tid; i < L * S; i += NT) t_x[i / S][i % S] = tgt[(i / S) * W + 6 + (i % S)];
+    __syncthreads();
+    if (tid < L) {
+        int n = 0;
+        for (int k = 0; k < S; ++k) { const float t = t_x[tid][k]; n += !((t < 0.f) || (t >= img_w)); }
+        t_len[tid] = (float)n;
+    }
+    __syncthreads();
+
+    // ---- per-anchor raw terms ------------------------------------------------------------------------------
+    float dist[MAXL], start[MAXL], theta[MAXL], iou[MAXL], cls = 0.f;
+    float mx_d = -INFINITY, mx_s = -INFINITY, mx_t = -INFINITY;
+    const bool arow = tid < N;
+    if (arow) {
+        const float* p = pred + (size_t)tid * W;
+        // focal cost of the positive class (focal_cost: alpha .25, gamma 2, eps 1e-12), label column 1
+        const float pr = 1.0f / (1.0f + expf(-p[1]));
+        const float negc = -logf(1.0f - pr + 1e-12f) * 0.75f * (pr * pr);
+        const float posc = -logf(pr + 1e-12f) * 0.25f * ((1.0f - pr) * (1.0f - pr));
+        cls = posc - negc;
+        const float psy = p[2] * (img_h - 1.0f), psx = p[3] * (img_w - 1.0f), pth = p[4];
+#pragma unroll
+        for (int j = 0; j < MAXL; ++j) {
+            dist[j] = start[j] = theta[j] = iou[j] = 0.f;
+            if (j >= L || !t_valid[j]) continue;
+            float d = 0.f, ovr = 0.f, uni = 0.f;
+            for (int k = 0; k < S; ++k) {
+                const float t = t_x[j][k];
+                if ((t < 0.f) || (t >= img_w)) continue;
+                const float x = p[6 + k] * (img_w - 1.0f);
+                d += fabsf(t - x);
+                ovr += fminf(x + 15.f, t + 15.f) - fmaxf(x - 15.f, t - 15.f);
+                uni += fmaxf(x + 15.f, t + 15.f) - fminf(x - 15.f, t - 15.f);
+            }
+            dist[j] = d / (t_len[j] + 1e-9f);
+            iou[j] = ovr / (uni + 1e-9f);
+            const float* tr = tgt + (size_t)j * W;
+            const float dy = psy - tr[2] * (img_h - 1.0f), dx = psx - tr[3] * (img_w - 1.0f);
+            start[j] = sqrtf(dy * dy + dx * dx);
+            theta[j] = fabsf(pth - tr[4]) * 180.f;
+            mx_d = fmaxf(mx_d, dist[j]); mx_s = fmaxf(mx_s, start[j]); mx_t = fmaxf(mx_t, theta[j]);
+        }
+    }
+    mx_d = block_max(mx_d, red);
+    mx_s = block_max(mx_s, red);
+    mx_t = block_max(mx_t, red);
+    if (arow) {
+#pragma unroll
+        for (int j = 0; j < MAXL; ++j) {
+            float c = INFINITY;
+            if (j < L && t_valid[j]) {
+                const float a = 1.0f - dist[j] / (mx_d + 1e-4f);
+                const float b = 1.0f - start[j] / (mx_s + 1e-4f);
+                const float t = 1.0f - theta[j] / (mx_t + 1e-4f);
+                const float prod = a * b * t;
+                c = -(prod * prod) * 3.0f + cls - iou[j];
+            }
+            cost[tid * MAXL + j] = c;
+            if (cost_out && j < L) cost_out[(size_t)tid * L + j] = c;
+        }
+    }
+    __syncthreads();
+
+    // ---- the MAXL cheapest rows of every valid column (wave j <-> column j) -----------------------------------
+    {
+        const int j = tid >> 6, lane = tid & 63;
+        if (j < MAXL) {
+            const bool valid = j < L && t_valid[j];
+            for (int r = 0; r < MAXL; ++r) {
+                float bv = INFINITY; int bi = 0x7fffffff;
+                if (valid)
+                    for (int i = lane; i < N; i += 64) {
+                        bool taken = false;
+                        for (int q = 0; q < r; ++q) taken |= (top_rows[j][q] == i);
+                        const float c = cost[i * MAXL + j];
+                        if (!taken && (c < bv || (c == bv && i < bi))) { bv = c; bi = i; }
+                    }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    const float ov = __shfl_xor(bv, off, 64);
+                    const int oi = __shfl_xor(bi, off, 64);
+                    if (ov < bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+                }
+                if (lane == 0) top_rows[j][r] = valid ? bi : -1;
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- enumerate candidate combinations: thread t <-> (t&3, (t>>2)&3, (t>>4)&3, t>>6) -----------------------
+    {
+        int rows[MAXL];
+        float total = 0.f;
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < MAXL; ++j) {
+            const int pick = (tid >> (2 * j)) & 3;
+            const bool valid = j < L && t_valid[j];
+            rows[j] = valid ? top_rows[j][pick] : -1;
+            if (!valid) { ok = ok && pick == 0; continue; }          // one representative per invalid column
+            if (rows[j] < 0 || rows[j] == 0x7fffffff) { ok = false; continue; }
+            total += cost[rows[j] * MAXL + j];
+#pragma unroll
+            for (int q = 0; q < j; ++q) ok = ok && !(rows[q] >= 0 && rows[q] == rows[j]);
+        }
+        combo_cost[tid] = ok ? total : INFINITY;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        float bv = INFINITY; int bi = 0x7fffffff;
+        for (int c = tid; c < NT; c += 64) {
+            const float v = combo_cost[c];
+            if (v < bv || (v == bv && c < bi)) { bv = v; bi = c; }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ov = __shfl_xor(bv, off, 64);
+            const int oi = __shfl_xor(bi, off, 64);
+            if (ov < bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (tid == 0) best_combo = bi;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int rows[MAXL], nv = 0;
+        for (int j = 0; j < MAXL; ++j) {
+            const bool valid = j < L && t_valid[j];
+            rows[j] = (valid && best_combo != 0x7fffffff) ? top_rows[j][(best_combo >> (2 * j)) & 3] : -1;
+            if (j < L) rows_by_col[j] = rows[j];
+            nv += rows[j] >= 0;
+        }
+        // ascending valid rows first (prior-index order, as scipy returns them), then -1
+        for (int a = 0; a < MAXL; ++a)
+            for (int b = a + 1; b < MAXL; ++b) {
+                const bool swap = (rows[b] >= 0) && (rows[a] < 0 || rows[b] < rows[a]);
+                if (swap) { const int t = rows[a]; rows[a] = rows[b]; rows[b] = t; }
+            }
+        for (int j = 0; j < L; ++j) rows_sorted[j] = rows[j];
+        if (n_valid_out) *n_valid_out = nv;
+    }
+}
+
+
+}  // namespace phassign

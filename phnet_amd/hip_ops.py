@@ -413,3 +413,27 @@ def lane_assign(pred, tgt, img_w: int, img_h: int, want_cost: bool = False):
     check(lib().phnet_lane_assign(_ptr(pred), _ptr(tgt), n, L, w - 6, float(img_w), float(img_h), _ptr(rows), _ptr(srt),
                                   _ptr(nv), _ptr(cost), _stream()), "phnet_lane_assign")
     return (rows, srt, nv, cost) if want_cost else (rows, srt, nv)
+
+
+def frame_loss(preds, gates, tgt, img_w, img_h, cls_w, reg_w, iou_w, liou_hw, liou_h, liou_w):
+    """preds: 6 x [N,6+S] (branch A stages 0..2, branch B stages 0..2), gates: 3 x [N], tgt [L,6+S].
+    Returns (loss [1], dpred [6,N,6+S], dgate [3,N], rows_by_col [6,L] i64, rows_sorted [6,L] i64)."""
+    import ctypes
+    for t in list(preds) + list(gates) + [tgt]:
+        _req(t, name="loss input")
+    n, w = preds[0].shape
+    L = tgt.shape[0]
+    dev = tgt.device
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    dpred = torch.empty((6, n, w), dtype=torch.float32, device=dev)
+    dgate = torch.empty((3, n), dtype=torch.float32, device=dev)
+    rows = torch.empty((6, L), dtype=torch.int64, device=dev)
+    srt = torch.empty((6, L), dtype=torch.int64, device=dev)
+    scratch = torch.empty(6 * n + 12, dtype=torch.float32, device=dev)
+    P = (ctypes.c_void_p * 6)(*[t.data_ptr() for t in preds])
+    G = (ctypes.c_void_p * 3)(*[t.data_ptr() for t in gates])
+    D = (ctypes.c_void_p * 6)(*[dpred[i].data_ptr() for i in range(6)])
+    check(lib().phnet_frame_loss(P, G, _ptr(tgt), n, L, w - 6, float(img_w), float(img_h), float(cls_w), float(reg_w),
+                                 float(iou_w), float(liou_hw), float(liou_h), float(liou_w), _ptr(loss), D, _ptr(dgate),
+                                 _ptr(rows), _ptr(srt), _ptr(scratch), _ptr(scratch[6 * n:]), _stream()), "phnet_frame_loss")
+    return loss, dpred, dgate, rows, srt

@@ -14,6 +14,28 @@ import torch.nn.functional as F
 from phnet_amd import hip_ops as K
 
 
+class _FusedFrameLoss(torch.autograd.Function):
+    """(6 predictions, 3 gates) -> frame loss: phnet_frame_loss computes the value and every input gradient in two launches."""
+
+    @staticmethod
+    def forward(ctx, crit, tgt, *tensors):
+        preds = [t.reshape(-1, t.shape[-1]).contiguous() for t in tensors[:6]]
+        gates = [t.reshape(-1).contiguous() for t in tensors[6:]]
+        loss, dpred, dgate, _, rows_sorted = K.frame_loss(
+            preds, gates, tgt.contiguous(), crit.img_w, crit.img_h, crit.cls_weight, crit.reg_weight, crit.iou_weight,
+            crit.liou_half_width, crit.liou_img_h, crit.liou_img_w)
+        ctx.save_for_backward(dpred, dgate)
+        ctx.pshape, ctx.gshape = tensors[0].shape, tensors[6].shape
+        ctx.mark_non_differentiable(rows_sorted)
+        return loss.view(()), rows_sorted
+
+    @staticmethod
+    def backward(ctx, gloss, _rows):
+        dpred, dgate = ctx.saved_tensors
+        dp, dg = dpred * gloss, dgate * gloss
+        return (None, None, *[dp[i].view(ctx.pshape) for i in range(6)], *[dg[i].view(ctx.gshape) for i in range(3)])
+
+
 class Criterion4OL(nn.Module):
     def __init__(self, cfg):
         super().__init__()
@@ -25,6 +47,7 @@ class Criterion4OL(nn.Module):
         # LaneIoULoss() is built with its class defaults, not cfg (dynamic_assignV2.py:56; loss4OLV3.py:28)
         self.liou_half_width, self.liou_img_h, self.liou_img_w = 7.5 / 768, 400, 960
         self._consts = {}
+        self.fused = True          # phnet_frame_loss (2 launches / frame); False -> tensor-op spelling
 
     def _const(self, key, values, like):
         k = (key, like.device)
@@ -81,6 +104,16 @@ class Criterion4OL(nn.Module):
 
     def loss4OneStep(self, output, batch, diff=None):
         assert diff is not None
+        targets = batch["lane_line"]
+        fa, fb = output["predictions_fir"], output["predictions_sec"]
+        if (self.fused and targets.shape[0] == 1 and len(fa) == 3 and len(fb) == 3 and targets.shape[1] <= 4
+                and fa[0].shape[-2] <= 256 and fa[0].is_cuda):
+            loss, rows_sorted = _FusedFrameLoss.apply(self, targets[0], *fa, *fb, *diff)
+            return [rows_sorted[3], rows_sorted[4], rows_sorted[5]], loss
+        return self.loss4OneStep_tensor_ops(output, batch, diff)
+
+    def loss4OneStep_tensor_ops(self, output, batch, diff=None):
+        """The same criterion spelled out in device tensor ops (used as the cross-check of the fused kernel)."""
         targets = batch["lane_line"]
         _, cls_a, reg_a, iou_a = self.line_loss_diff(output["predictions_fir"], targets)
         matched_b, cls_b, reg_b, iou_b = self.line_loss_diff(output["predictions_sec"], targets)

@@ -296,3 +296,43 @@ def test_arena_direct_accumulation_equals_autograd_accumulation():
             assert float((a.grad - b.grad).abs().max()) <= 2e-3 * scale, (k, float((a.grad - b.grad).abs().max()), scale)
     finally:
         arena.release()
+
+
+def test_fused_frame_loss_equals_tensor_op_criterion():
+    """phnet_frame_loss (value + all input gradients) against the same criterion spelled in tensor ops + autograd."""
+    from phnet_amd.config import make_cfg
+    from phnet_amd.libs.utils.loss4OLV3 import Criterion4OL
+    g = O.Geometry()
+    crit = Criterion4OL(make_cfg())
+    r = np.random.default_rng(7)
+    pri, _ = O.priors_from_embeddings(O.initial_anchor_embeddings(g), g)
+    for n_lanes in (3, 4, 1, 0):
+        tgt = synth.make_targets(g, 1, n_lanes=max(n_lanes, 1)).cuda()
+        if n_lanes == 0:
+            tgt[0, :, :] = -1e5; tgt[0, :, 0] = 1; tgt[0, :, 1] = 0
+
+        def mk():
+            t = pri.clone()
+            t[:, :2] = torch.from_numpy(r.normal(0, 1, (240, 2)).astype(np.float32))
+            t[:, 2:5] += torch.from_numpy(r.normal(0, 0.02, (240, 3)).astype(np.float32))
+            t[:, 5] = torch.from_numpy(r.uniform(0.3, 0.9, 240).astype(np.float32))
+            t[:, 6:] += torch.from_numpy(r.normal(0, 0.01, (240, 36)).astype(np.float32))
+            return t.unsqueeze(0).cuda().requires_grad_(True)
+        preds = [mk() for _ in range(6)]
+        gates = [torch.from_numpy(r.uniform(0.5, 1.0, (1, 240, 1)).astype(np.float32)).cuda().requires_grad_(True) for _ in range(3)]
+        out = {"predictions_fir": preds[:3], "predictions_sec": preds[3:]}
+        crit.fused = False
+        m_ref, l_ref = crit(out, tgt, gates)
+        (l_ref * 0.2).backward()
+        ref_g = [t.grad.clone() for t in preds + gates]
+        for t in preds + gates:
+            t.grad = None
+        crit.fused = True
+        m_fu, l_fu = crit(out, tgt, gates)
+        (l_fu * 0.2).backward()
+        assert abs(float(l_fu) - float(l_ref)) <= 1e-4 * abs(float(l_ref)) + 1e-5, (n_lanes, float(l_fu), float(l_ref))
+        for a, b in zip(m_fu, m_ref):
+            assert a.cpu().tolist() == b.cpu().tolist()
+        for i, (t, gr) in enumerate(zip(preds + gates, ref_g)):
+            scale = float(gr.abs().max()) + 1e-8
+            assert float((t.grad - gr).abs().max()) <= 2e-4 * scale + 1e-7, (n_lanes, i, float((t.grad - gr).abs().max()), scale)
