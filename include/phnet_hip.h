@@ -62,8 +62,10 @@ int phnet_conv2d_fwd(const float* x, const float* w, const float* bias, float* y
 int phnet_conv2d_dgrad(const float* dy, const float* w, const float* addend, float* dx,
                        int32_t N, int32_t Hi, int32_t Wi, int32_t Ci, int32_t Co, int32_t R, int32_t S,
                        int32_t stride, int32_t pad, void* workspace, uint64_t ws_bytes, void* stream);
-/* host-side query (no device work; bm/bn/splits are HOST pointers): tile and split-K factor the two calls above use. */
-int phnet_conv2d_plan(int64_t M, int32_t Co, int32_t K, uint64_t ws_bytes, int32_t* bm, int32_t* bn, int32_t* splits);
+/* host-side query (no device work; bm/bn/splits/k_tile are HOST pointers): tile, split-K factor and K-tile depth the
+ * two calls above use, i.e. the template arguments of the conv_igemm_kernel<BM, BN, DGRAD, BKT> they launch. */
+int phnet_conv2d_plan(int64_t M, int32_t Co, int32_t K, uint64_t ws_bytes, int32_t* bm, int32_t* bn, int32_t* splits,
+                      int32_t* k_tile);
 /* tuning aid for benchmarks only (process-global): force tile/split-K of the next fwd/dgrad calls; bm=0 -> heuristic. */
 int phnet_tune_force_conv_tile(int32_t bm, int32_t bn, int32_t splits);
 uint64_t phnet_conv2d_wgrad_workspace(int32_t N, int32_t Hi, int32_t Wi, int32_t Ci, int32_t Co,
@@ -141,6 +143,14 @@ int phnet_frame_loss(const float* const* pred, const float* const* gate, const f
                      float liou_half_width, float liou_img_h, float liou_img_w,
                      float* loss, float* const* dpred, float* dgate,
                      int64_t* rows_by_col, int64_t* rows_sorted, float* focal, float* scalars, void* stream);
+
+/* ---- lane prior update: replaces the tanh/tan/repeat/cat chain of forward_first/second (Router4OL.py:328-345) and its
+ * backward.  priors [N][6+S]; head [N][HW] = (cls 2 | reg 4 | offsets S | zero pad); ys [S] = prior_ys. ---- */
+int phnet_lane_update_fwd(const float* priors, const float* head, const float* ys, float* preds, float* lines,
+                          int32_t N, int32_t S, int32_t HW, float img_w, float img_h, void* stream);
+int phnet_lane_update_bwd(const float* dpreds, const float* dlines, const float* lines, const float* head,
+                          const float* ys, float* dhead, float* dpriors,
+                          int32_t N, int32_t S, int32_t HW, float img_w, float img_h, void* stream);
 
 /* ---- ReLU backward through the saved output (fused-ReLU epilogues of the linears) ---- */
 int phnet_relu_bwd(const float* dy, const float* y, float* dx, int64_t n, void* stream);

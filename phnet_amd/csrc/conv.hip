@@ -34,18 +34,21 @@ struct ConvShape {
 
 struct RowCoord { int base, iy0, ix0; bool ok; };
 
-template <int BM, int BN, bool B_DGRAD>
+template <int BM, int BN, bool B_DGRAD, int BKT>
 __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(
     const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ bias,
     const float* __restrict__ addend, float* __restrict__ out, ConvShape g, int relu)
 {
     constexpr int TM = BM / 2, TN = BN / 2, FM = TM / 32, FN = TN / 32;
-    constexpr int A_FLOATS = KContigTile<BM>::FLOATS;
-    constexpr int B_PITCH = KStridedTile<BN>::PITCH;
-    constexpr int B_FLOATS = B_DGRAD ? KStridedTile<BN>::FLOATS : KContigTile<BN>::FLOATS;
-    constexpr int A_LOADS = BM / 64;                    // float4 loads per thread per K step
-    constexpr int B_LOADS = BN / 64;
-    __shared__ __attribute__((aligned(16))) float lds[2 * (A_FLOATS + B_FLOATS)];
+    constexpr int A_PITCH = KContigTile<BM, BKT>::PITCH;
+    constexpr int A_FLOATS = KContigTile<BM, BKT>::FLOATS;
+    constexpr int B_PITCH = B_DGRAD ? KStridedTile<BN, BKT>::PITCH : KContigTile<BN, BKT>::PITCH;
+    constexpr int B_FLOATS = B_DGRAD ? KStridedTile<BN, BKT>::FLOATS : KContigTile<BN, BKT>::FLOATS;
+    constexpr int CHUNKS = BKT / 4;                         // float4 chunks along K per row
+    constexpr int ROWS_PER_PASS = THREADS / CHUNKS;         // 64 (BKT 16) or 16 (BKT 64)
+    constexpr int A_LOADS = BM / ROWS_PER_PASS;             // float4 loads per thread per K tile
+    constexpr int B_LOADS = B_DGRAD ? (BKT * BN / 4) / THREADS : BN / ROWS_PER_PASS;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
     float* As = lds;
     float* Bs = lds + 2 * A_FLOATS;
 
@@ -61,10 +64,10 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(
 
     // ---- per-thread gather coordinates of the A rows this thread stages (fixed over the K loop) ----
     RowCoord rc[A_LOADS];
-    const int a_chunk = tid & 3;
+    const int a_chunk = tid % CHUNKS, a_row = tid / CHUNKS;
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i) {
-        const int m = m0 + (tid >> 2) + 64 * i;
+        const int m = m0 + a_row + ROWS_PER_PASS * i;
         rc[i].ok = m < M;
         const int mm = rc[i].ok ? m : 0;
         const int n = mm / (g.Ho * g.Wo), rem = mm - n * (g.Ho * g.Wo);
@@ -75,7 +78,7 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(
     }
 
     // ---- running (tap, channel) decomposition of this thread's k index: one division at start-up, then
-    // carry-propagating adds per K step (the per-step integer divisions made the loop VALU-bound) ----------
+    // carry-propagating adds per K tile (per-step integer divisions made the loop VALU-bound) ----------
     struct KPos { int c, r, q; };
     auto kpos_init = [&](int k, int ci) {
         KPos p;
@@ -86,7 +89,7 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(
         return p;
     };
     auto kpos_advance = [&](KPos& p, int ci) {
-        p.c += BK;
+        p.c += BKT;
         while (p.c >= ci) {
             p.c -= ci;
             if (++p.q == g.S) { p.q = 0; ++p.r; }
@@ -98,7 +101,7 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(
     if (B_DGRAD) {
 #pragma unroll
         for (int i = 0; i < B_LOADS; ++i) {
-            const int idx = tid + THREADS * i;                     // BK rows x BN/4 chunks
+            const int idx = tid + THREADS * i;                     // BKT rows x BN/4 chunks
             b_kk[i] = idx / (BN / 4);
             b_ch[i] = idx - b_kk[i] * (BN / 4);
             kb[i] = kpos_init(k_begin + b_kk[i], g.Ci);
@@ -106,9 +109,9 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(
     }
 
     f32x4 a_reg[A_LOADS], b_reg[B_LOADS];
-    // loads the K step that starts at kt; MUST be called with kt = k_begin, k_begin+BK, ... in order
+    // loads the K tile that starts at kt; MUST be called with kt = k_begin, k_begin+BKT, ... in order
     auto load_global = [&](int kt) {
-        // A: 4 consecutive lanes fetch the 64 contiguous bytes (16 channels) of one pixel tap
+        // A: CHUNKS consecutive lanes fetch BKT*4 contiguous bytes of one pixel tap
         const int k0 = kt + a_chunk * 4;
         const bool kok = k0 < k_end;
 #pragma unroll
@@ -131,7 +134,7 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(
             // B rows = output channels, K contiguous in the OHWI weight
 #pragma unroll
             for (int i = 0; i < B_LOADS; ++i) {
-                const int n = n0 + (tid >> 2) + 64 * i;
+                const int n = n0 + a_row + ROWS_PER_PASS * i;
                 b_reg[i] = (kok && n < g.Co) ? *reinterpret_cast<const f32x4*>(W + (size_t)n * K + k0)
                                              : f32x4{0.f, 0.f, 0.f, 0.f};
             }
@@ -154,11 +157,11 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(
         float* b = Bs + buf * B_FLOATS;
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i)
-            *reinterpret_cast<f32x4*>(a + ((tid >> 2) + 64 * i) * LDK + a_chunk * 4) = a_reg[i];
+            *reinterpret_cast<f32x4*>(a + (a_row + ROWS_PER_PASS * i) * A_PITCH + a_chunk * 4) = a_reg[i];
         if (!B_DGRAD) {
 #pragma unroll
             for (int i = 0; i < B_LOADS; ++i)
-                *reinterpret_cast<f32x4*>(b + ((tid >> 2) + 64 * i) * LDK + a_chunk * 4) = b_reg[i];
+                *reinterpret_cast<f32x4*>(b + (a_row + ROWS_PER_PASS * i) * B_PITCH + a_chunk * 4) = b_reg[i];
         } else {
 #pragma unroll
             for (int i = 0; i < B_LOADS; ++i)
@@ -179,14 +182,18 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(
         store_lds(0);
         __syncthreads();
         int buf = 0;
-        for (int kt = k_begin; kt < k_end; kt += BK) {
-            const bool more = kt + BK < k_end;
-            if (more) load_global(kt + BK);
-            float a[FM][8], b[FN][8];
-            read_kcontig<FM>(As + buf * A_FLOATS + wm * LDK, lane, a);
-            if (!B_DGRAD) read_kcontig<FN>(Bs + buf * B_FLOATS + wn * LDK, lane, b);
-            else read_kstrided<FN, B_PITCH>(Bs + buf * B_FLOATS + wn, lane, b);
-            mma_step<FM, FN>(a, b, acc);
+        for (int kt = k_begin; kt < k_end; kt += BKT) {
+            const bool more = kt + BKT < k_end;
+            if (more) load_global(kt + BKT);
+#pragma unroll
+            for (int ks = 0; ks < BKT / BK; ++ks) {
+                if (BKT > BK && kt + ks * BK >= k_end) break;          // ragged K tail of a deep tile
+                float a[FM][8], b[FN][8];
+                read_kcontig<FM, A_PITCH>(As + buf * A_FLOATS + wm * A_PITCH, lane, ks, a);
+                if (!B_DGRAD) read_kcontig<FN, B_PITCH>(Bs + buf * B_FLOATS + wn * B_PITCH, lane, ks, b);
+                else read_kstrided<FN, B_PITCH>(Bs + buf * B_FLOATS + wn, lane, ks, b);
+                mma_step<FM, FN>(a, b, acc);
+            }
             if (more) store_lds(buf ^ 1);
             __syncthreads();
             buf ^= 1;
@@ -248,8 +255,8 @@ __global__ __launch_bounds__(THREADS) void conv_wgrad_kernel(
     const float* __restrict__ dY, const float* __restrict__ X, float* __restrict__ out, WgradShape g)
 {
     constexpr int TM = BM / 2, TN = BN / 2, FM = TM / 32, FN = TN / 32;
-    constexpr int A_PITCH = KStridedTile<BM>::PITCH, B_PITCH = KStridedTile<BN>::PITCH;
-    constexpr int A_FLOATS = KStridedTile<BM>::FLOATS, B_FLOATS = KStridedTile<BN>::FLOATS;
+    constexpr int A_PITCH = KStridedTile<BM, BK>::PITCH, B_PITCH = KStridedTile<BN, BK>::PITCH;
+    constexpr int A_FLOATS = KStridedTile<BM, BK>::FLOATS, B_FLOATS = KStridedTile<BN, BK>::FLOATS;
     constexpr int A_LOADS = BM / 64, B_LOADS = BN / 64;      // BK*BM/4 float4 over 256 threads
     __shared__ __attribute__((aligned(16))) float lds[2 * (A_FLOATS + B_FLOATS)];
     float* As = lds;
@@ -347,8 +354,8 @@ __global__ __launch_bounds__(THREADS) void conv_wgrad_kernel(
             const bool more = pt + BK < p_end;
             if (more) load_global(pt + BK);
             float a[FM][8], b[FN][8];
-            read_kstrided<FM, A_PITCH>(As + buf * A_FLOATS + wm, lane, a);
-            read_kstrided<FN, B_PITCH>(Bs + buf * B_FLOATS + wn, lane, b);
+            read_kstrided<FM, A_PITCH>(As + buf * A_FLOATS + wm, lane, 0, a);
+            read_kstrided<FN, B_PITCH>(Bs + buf * B_FLOATS + wn, lane, 0, b);
             mma_step<FM, FN>(a, b, acc);
             if (more) store_lds(buf ^ 1);
             __syncthreads();
@@ -439,17 +446,37 @@ int launch_conv(const float* X, const float* W, const float* bias, const float* 
     const ConvPlan t = plan_conv(M, g.Co, K, workspace != nullptr, ws_bytes);
     const long tiles = t.tiles;
     const int splits = t.splits;
-    const int ksteps = (K + BK - 1) / BK;
     g.splits = splits;
-    g.k_per_split = ((ksteps + splits - 1) / splits) * BK;
     float* dst = splits > 1 ? workspace : out;
     dim3 grid((unsigned)tiles, 1, (unsigned)splits);
-#define PHNET_LAUNCH_CONV(BM_, BN_) \
-    hipLaunchKernelGGL((conv_igemm_kernel<BM_, BN_, DGRAD>), grid, dim3(THREADS), 0, st, X, W, bias, addend, dst, g, relu)
+    // deep K tiles for skinny (latency-bound) problems: few row tiles and K long enough to fill them
+    const bool deep = M <= 2048 && K >= 64;
+    const int bkt = deep ? 64 : BK;
+    const int ksteps = (K + bkt - 1) / bkt;
+    g.k_per_split = ((ksteps + splits - 1) / splits) * bkt;
+#define PHNET_LAUNCH_CONV_(BM_, BN_, BKT_)                                                                              \
+    do {                                                                                                                \
+        constexpr size_t lds_ = 2 * (KContigTile<BM_, BKT_>::FLOATS +                                                   \
+                                     (DGRAD ? KStridedTile<BN_, BKT_>::FLOATS : KContigTile<BN_, BKT_>::FLOATS)) * 4;   \
+        static bool attr_set_ = false;                                                                                  \
+        if (lds_ > 64 * 1024 && !attr_set_) {                                                                           \
+            hipFuncSetAttribute((const void*)conv_igemm_kernel<BM_, BN_, DGRAD, BKT_>,                                  \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_);                                 \
+            attr_set_ = true;                                                                                           \
+        }                                                                                                               \
+        hipLaunchKernelGGL((conv_igemm_kernel<BM_, BN_, DGRAD, BKT_>), grid, dim3(THREADS), lds_, st, X, W, bias,       \
+                           addend, dst, g, relu);                                                                       \
+    } while (0)
+#define PHNET_LAUNCH_CONV(BM_, BN_)                                                                                     \
+    do {                                                                                                                \
+        if (deep) PHNET_LAUNCH_CONV_(BM_, BN_, 64);                                                                     \
+        else PHNET_LAUNCH_CONV_(BM_, BN_, 16);                                                                          \
+    } while (0)
     if (t.bm == 128 && t.bn == 128) PHNET_LAUNCH_CONV(128, 128);
     else if (t.bm == 128 && t.bn == 64) PHNET_LAUNCH_CONV(128, 64);
     else if (t.bm == 64 && t.bn == 128) PHNET_LAUNCH_CONV(64, 128);
     else PHNET_LAUNCH_CONV(64, 64);
+#undef PHNET_LAUNCH_CONV_
 #undef PHNET_LAUNCH_CONV
     if (splits > 1) {
         const long total4 = M * g.Co / 4;
@@ -463,11 +490,13 @@ int launch_conv(const float* X, const float* W, const float* bias, const float* 
 
 // Which kernel instantiation / split-K factor phnet_conv2d_fwd / _dgrad will use for a GEMM of M x Co x K
 // (profiling aid for bench.py: lets the host attribute event timings to one kernel symbol).
-PHNET_API int phnet_conv2d_plan(int64_t M, int32_t Co, int32_t K, uint64_t ws_bytes, int32_t* bm, int32_t* bn, int32_t* splits)
+PHNET_API int phnet_conv2d_plan(int64_t M, int32_t Co, int32_t K, uint64_t ws_bytes, int32_t* bm, int32_t* bn, int32_t* splits,
+                                int32_t* k_tile)
 {
-    if (M < 1 || Co < 1 || K < 1 || !bm || !bn || !splits) return PHNET_ERR_ARG;
+    if (M < 1 || Co < 1 || K < 1 || !bm || !bn || !splits || !k_tile) return PHNET_ERR_ARG;
     const ConvPlan p = plan_conv((long)M, Co, K, ws_bytes > 0, (size_t)ws_bytes);
     *bm = p.bm; *bn = p.bn; *splits = p.splits;
+    *k_tile = (M <= 2048 && K >= 64) ? 64 : BK;
     return PHNET_OK;
 }
 

@@ -10,7 +10,101 @@ __global__ __launch_bounds__(NT) void relu_bwd_kernel(const float* __restrict__ 
     const long i = (long)blockIdx.x * NT + threadIdx.x;
     if (i < n) dx[i] = y[i] > 0.f ? dy[i] : 0.f;
 }
+// ---- lane prior update (Router4OL.py:328-345): one thread per anchor ------------------------------------------
+// head [N][HW] = (cls 2 | reg 4 | offsets S | pad); priors [N][6+S]; ys [S] = prior_ys
+// lines = (cls, start_y/start_x/theta + tanh(reg[:3]), reg[3], xs(line));  preds = lines with xs + offsets
+__global__ __launch_bounds__(NT) void lane_update_fwd_kernel(const float* __restrict__ priors, const float* __restrict__ head,
+                                                             const float* __restrict__ ys, float* __restrict__ preds,
+                                                             float* __restrict__ lines, int N, int S, int HW, float img_w, float img_h)
+{
+    // no fused multiply-adds here: theta*pi + 1e-5 sits next to tan's poles for near-horizontal anchors, where one
+    // rounding more or less in the angle moves x by 1e-3; the reference rounds after the multiply and after the add
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= N) return;
+    const int W = 6 + S;
+    const float* pr = priors + (size_t)i * W;
+    const float* hd = head + (size_t)i * HW;
+    float* po = preds + (size_t)i * W;
+    float* lo = lines + (size_t)i * W;
+    const float sy = pr[2] + tanhf(hd[2]), sx = pr[3] + tanhf(hd[3]), th = pr[4] + tanhf(hd[4]);
+    const float tn = tanf(th * 3.14159265358979323846f + 1e-5f);
+    po[0] = lo[0] = hd[0]; po[1] = lo[1] = hd[1];
+    po[2] = lo[2] = sy; po[3] = lo[3] = sx; po[4] = lo[4] = th; po[5] = lo[5] = hd[5];
+    for (int k = 0; k < S; ++k) {
+        const float x = (sx * (img_w - 1.0f) + ((1.0f - ys[k] - sy) * img_h / tn)) / (img_w - 1.0f);
+        lo[6 + k] = x;
+        po[6 + k] = x + hd[6 + k];
+    }
+}
+
+__global__ __launch_bounds__(NT) void lane_update_bwd_kernel(const float* __restrict__ dpreds, const float* __restrict__ dlines,
+                                                             const float* __restrict__ lines, const float* __restrict__ head,
+                                                             const float* __restrict__ ys, float* __restrict__ dhead,
+                                                             float* __restrict__ dpriors, int N, int S, int HW, float img_w, float img_h)
+{
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= N) return;
+    const int W = 6 + S;
+    const float* dp = dpreds ? dpreds + (size_t)i * W : nullptr;
+    const float* dl = dlines ? dlines + (size_t)i * W : nullptr;
+    const float* ln = lines + (size_t)i * W;
+    const float* hd = head + (size_t)i * HW;
+    float* dh = dhead + (size_t)i * HW;
+    auto G = [&](int c) { return (dp ? dp[c] : 0.f) + (dl ? dl[c] : 0.f); };
+    const float sy = ln[2], th = ln[4];
+    const float ang = th * 3.14159265358979323846f + 1e-5f;
+    const float tn = tanf(ang), sn = sinf(ang);
+    float gsy = G(2), gsx = G(3), gth = G(4);
+    const float kx = img_h / (img_w - 1.0f);
+    for (int k = 0; k < S; ++k) {
+        const float gx = G(6 + k);
+        gsx += gx;
+        gsy += gx * (-kx / tn);
+        gth += gx * (-(1.0f - ys[k] - sy) * kx * 3.14159265358979323846f / (sn * sn));
+        dh[6 + k] = dp ? dp[6 + k] : 0.f;
+    }
+    dh[0] = G(0); dh[1] = G(1);
+    const float t2 = tanhf(hd[2]), t3 = tanhf(hd[3]), t4 = tanhf(hd[4]);
+    dh[2] = gsy * (1.0f - t2 * t2);
+    dh[3] = gsx * (1.0f - t3 * t3);
+    dh[4] = gth * (1.0f - t4 * t4);
+    dh[5] = G(5);
+    for (int c = W; c < HW; ++c) dh[c] = 0.f;
+    if (dpriors) {
+        float* d = dpriors + (size_t)i * W;
+        d[0] = d[1] = 0.f; d[2] = gsy; d[3] = gsx; d[4] = gth; d[5] = 0.f;
+        for (int k = 0; k < S; ++k) d[6 + k] = 0.f;
+    }
+}
 }  // namespace
+
+// Lane prior update: replaces the tanh / tan / repeat / cat chain of DetNetV2.forward_first/second (Router4OL.py:328-345).
+// priors [N][6+S], head [N][HW] (cls 2, reg 4, offsets S, zero pad; HW >= 6+S), ys [S] -> preds, lines [N][6+S].
+PHNET_API int phnet_lane_update_fwd(const float* priors, const float* head, const float* ys, float* preds, float* lines,
+                                    int32_t N, int32_t S, int32_t HW, float img_w, float img_h, void* stream)
+{
+    if (N < 0 || S < 1 || HW < 6 + S) return PHNET_ERR_ARG;
+    if (N == 0) return PHNET_OK;
+    if (!priors || !head || !ys || !preds || !lines) return PHNET_ERR_ARG;
+    hipLaunchKernelGGL(lane_update_fwd_kernel, dim3((N + NT - 1) / NT), dim3(NT), 0, (hipStream_t)stream,
+                       priors, head, ys, preds, lines, N, S, HW, img_w, img_h);
+    return phnet_launch_status();
+}
+
+// dpreds / dlines [N][6+S] (either may be NULL) -> dhead [N][HW]; dpriors [N][6+S] optional (only cols 2..4 non-zero).
+PHNET_API int phnet_lane_update_bwd(const float* dpreds, const float* dlines, const float* lines, const float* head,
+                                    const float* ys, float* dhead, float* dpriors,
+                                    int32_t N, int32_t S, int32_t HW, float img_w, float img_h, void* stream)
+{
+    if (N < 0 || S < 1 || HW < 6 + S) return PHNET_ERR_ARG;
+    if (N == 0) return PHNET_OK;
+    if (!lines || !head || !ys || !dhead || (!dpreds && !dlines)) return PHNET_ERR_ARG;
+    hipLaunchKernelGGL(lane_update_bwd_kernel, dim3((N + NT - 1) / NT), dim3(NT), 0, (hipStream_t)stream,
+                       dpreds, dlines, lines, head, ys, dhead, dpriors, N, S, HW, img_w, img_h);
+    return phnet_launch_status();
+}
 
 // dx = dy where y > 0 else 0 (ReLU backward through the saved output); dx may alias dy.
 PHNET_API int phnet_relu_bwd(const float* dy, const float* y, float* dx, int64_t n, void* stream)

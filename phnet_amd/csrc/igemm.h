@@ -5,14 +5,14 @@
 // (trainOL.py:21-22,225: GradScaler without autocast), so f32-input MFMA keeps its numerics.
 //
 // Tiling: 256 threads = 4 wavefronts in a 2x2 arrangement; block tile BM x BN (64 or 128 each), wave
-// tile (BM/2) x (BN/2) made of 32x32 MFMA fragments; K step 16, double-buffered in LDS with register
+// tile (BM/2) x (BN/2) made of 32x32 MFMA fragments; K tile 16 or 64, double-buffered in LDS with register
 // prefetch of the next step (one barrier per step).
 //
 // LDS images (conflict-free by construction, see MI355X_MICROARCH.md "LDS"):
-//   K-contiguous operand ([row][k]: im2col rows, [N][K] weights): [rows][20] floats; the fill is one
-//     ds_write_b128 per 4 k's, the fragment read is 2 x ds_read_b128 per 32-row fragment and K step
-//     (80-byte row pitch -> the 16 lanes of a b128 lane group hit 16 distinct 4-bank slots).
-//   K-strided operand ([k][col]: dY for wgrad, [K][N] right-hand sides): [16][cols+4] floats; fill is
+//   K-contiguous operand ([row][k]: im2col rows, [N][K] weights): [rows][BKT+4] floats; the fill is one
+//     ds_write_b128 per 4 k's, the fragment read is 2 x ds_read_b128 per 32-row fragment and 16-deep sub-step
+//     (80- or 272-byte row pitch -> the 16 lanes of a b128 lane group hit 16 distinct 4-bank slots).
+//   K-strided operand ([k][col]: dY for wgrad, [K][N] right-hand sides): [BKT][cols+4] floats; fill is
 //     ds_write_b128 along the columns, fragment read is ds_read_b32 (32 consecutive floats per half wave).
 // The MFMA k index of (lane half h, step s) is 8h+s for BOTH operands, which is what lets the
 // K-contiguous image be read with 128-bit loads.
@@ -24,35 +24,36 @@ namespace igemm {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BK = 16;
-constexpr int LDK = 20;          // row pitch (floats) of a K-contiguous LDS image
+constexpr int BK = 16;           // MFMA sub-step depth: 8 x v_mfma_f32_32x32x2 (k = 8h+s per lane half h)
 constexpr int THREADS = 256;
 
-template <int ROWS> struct KContigTile { static constexpr int FLOATS = ROWS * LDK; };
-template <int COLS> struct KStridedTile { static constexpr int PITCH = COLS + 4; static constexpr int FLOATS = BK * PITCH; };
+// A K tile is BKT = 16 or 64 deep.  BKT = 64 is for the latency-bound skinny problems of the lane head (M = 240):
+// four times fewer load -> barrier -> MFMA round trips, four times more bytes in flight per round.
+template <int ROWS, int BKT> struct KContigTile { static constexpr int PITCH = BKT + 4; static constexpr int FLOATS = ROWS * PITCH; };
+template <int COLS, int BKT> struct KStridedTile { static constexpr int PITCH = COLS + 4; static constexpr int FLOATS = BKT * PITCH; };
 
-// ---- fragment reads ---------------------------------------------------------------------------
-// K-contiguous image: fragment f covers rows [32f, 32f+32) of the wave's sub-tile.
-template <int F>
-__device__ __forceinline__ void read_kcontig(const float* tile, int lane, float (&frag)[F][8]) {
+// ---- fragment reads (sub-step ks of the tile covers k in [16 ks, 16 ks + 16)) ---------------------------------
+// K-contiguous image [rows][PITCH]: fragment f covers rows [32f, 32f+32) of the wave's sub-tile.
+template <int F, int PITCH>
+__device__ __forceinline__ void read_kcontig(const float* tile, int lane, int ks, float (&frag)[F][8]) {
     const int r = lane & 31, h = lane >> 5;
 #pragma unroll
     for (int f = 0; f < F; ++f) {
-        const f32x4* p = reinterpret_cast<const f32x4*>(tile + (f * 32 + r) * LDK + 8 * h);
+        const f32x4* p = reinterpret_cast<const f32x4*>(tile + (f * 32 + r) * PITCH + 16 * ks + 8 * h);
         const f32x4 lo = p[0], hi = p[1];
         frag[f][0] = lo.x; frag[f][1] = lo.y; frag[f][2] = lo.z; frag[f][3] = lo.w;
         frag[f][4] = hi.x; frag[f][5] = hi.y; frag[f][6] = hi.z; frag[f][7] = hi.w;
     }
 }
 
-// K-strided image: column c of fragment f, k = 8h+s.
+// K-strided image [BKT][PITCH]: column c of fragment f, k = 16 ks + 8h + s.
 template <int F, int PITCH>
-__device__ __forceinline__ void read_kstrided(const float* tile, int lane, float (&frag)[F][8]) {
+__device__ __forceinline__ void read_kstrided(const float* tile, int lane, int ks, float (&frag)[F][8]) {
     const int c = lane & 31, h = lane >> 5;
 #pragma unroll
     for (int f = 0; f < F; ++f)
 #pragma unroll
-        for (int s = 0; s < 8; ++s) frag[f][s] = tile[(8 * h + s) * PITCH + f * 32 + c];
+        for (int s = 0; s < 8; ++s) frag[f][s] = tile[(16 * ks + 8 * h + s) * PITCH + f * 32 + c];
 }
 
 template <int FM, int FN>

@@ -138,6 +138,33 @@ def roi_pool(fmap, xs, ys):
     return _RoiPool.apply(fmap, xs, ys)
 
 
+class _LaneUpdate(torch.autograd.Function):
+    """(priors [1,N,6+S], head [1,N,HW]) -> (preds, lines): prior update of both branches in one launch each way."""
+
+    @staticmethod
+    def forward(ctx, priors, head, ys, img_w, img_h):
+        p2 = priors.reshape(-1, priors.shape[-1]).contiguous()
+        h2 = head.reshape(-1, head.shape[-1]).contiguous()
+        preds, lines = K.lane_update_fwd(p2, h2, ys, img_w, img_h)
+        ctx.save_for_backward(lines, h2, ys)
+        ctx.geom, ctx.pshape, ctx.hshape = (img_w, img_h), priors.shape, head.shape
+        return preds.view(priors.shape), lines.view(priors.shape)
+
+    @staticmethod
+    def backward(ctx, dpreds, dlines):
+        lines, h2, ys = ctx.saved_tensors
+        dp = None if dpreds is None else dpreds.reshape(lines.shape).contiguous()
+        dl = None if dlines is None else dlines.reshape(lines.shape).contiguous()
+        if dp is None and dl is None:
+            return None, None, None, None, None
+        dhead, dpri = K.lane_update_bwd(dp, dl, lines, h2, ys, ctx.geom[0], ctx.geom[1], ctx.needs_input_grad[0])
+        return (None if dpri is None else dpri.view(ctx.pshape)), dhead.view(ctx.hshape), None, None, None
+
+
+def lane_update(priors, head, ys, img_w, img_h):
+    return _LaneUpdate.apply(priors, head, ys, img_w, img_h)
+
+
 # ---------------------------------------------------------------------------------------------------------
 # Ops still on ATen device kernels in this round (listed in DESIGN.md "Not yet hand-written"): the per-anchor
 # batched 36x64x128 products of the dynamic head and the 240 x <=40 attention core of branch B.

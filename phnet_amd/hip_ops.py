@@ -18,9 +18,10 @@ TIMER = None
 
 def _gemm_symbol(m, co, k, ws_bytes, dgrad):
     import ctypes
-    bm, bn, sp = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
-    check(lib().phnet_conv2d_plan(m, co, k, ws_bytes, ctypes.byref(bm), ctypes.byref(bn), ctypes.byref(sp)), "phnet_conv2d_plan")
-    return f"conv_igemm_kernel<{bm.value}, {bn.value}, {'true' if dgrad else 'false'}>", sp.value
+    bm, bn, sp, kt = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+    check(lib().phnet_conv2d_plan(m, co, k, ws_bytes, ctypes.byref(bm), ctypes.byref(bn), ctypes.byref(sp), ctypes.byref(kt)),
+          "phnet_conv2d_plan")
+    return f"conv_igemm_kernel<{bm.value}, {bn.value}, {'true' if dgrad else 'false'}, {kt.value}>", sp.value
 
 
 class _Timed:
@@ -437,3 +438,22 @@ def frame_loss(preds, gates, tgt, img_w, img_h, cls_w, reg_w, iou_w, liou_hw, li
                                  float(iou_w), float(liou_hw), float(liou_h), float(liou_w), _ptr(loss), D, _ptr(dgate),
                                  _ptr(rows), _ptr(srt), _ptr(scratch), _ptr(scratch[6 * n:]), _stream()), "phnet_frame_loss")
     return loss, dpred, dgate, rows, srt
+
+
+def lane_update_fwd(priors, head, ys, img_w, img_h):
+    """priors [N,6+S], head [N,HW] -> (preds, lines) [N,6+S]."""
+    _req(priors, name="priors"); _req(head, name="head")
+    n, w = priors.shape
+    preds, lines = torch.empty_like(priors), torch.empty_like(priors)
+    check(lib().phnet_lane_update_fwd(_ptr(priors), _ptr(head), _ptr(ys), _ptr(preds), _ptr(lines), n, w - 6, head.shape[1],
+                                      float(img_w), float(img_h), _stream()), "phnet_lane_update_fwd")
+    return preds, lines
+
+
+def lane_update_bwd(dpreds, dlines, lines, head, ys, img_w, img_h, need_dpriors: bool):
+    n, w = lines.shape
+    dhead = torch.empty_like(head)
+    dpriors = torch.empty_like(lines) if need_dpriors else None
+    check(lib().phnet_lane_update_bwd(_ptr(dpreds), _ptr(dlines), _ptr(lines), _ptr(head), _ptr(ys), _ptr(dhead), _ptr(dpriors),
+                                      n, w - 6, head.shape[1], float(img_w), float(img_h), _stream()), "phnet_lane_update_bwd")
+    return dhead, dpriors

@@ -174,9 +174,7 @@ class DetNetV2(nn.Module):
         h = PF.linear(feat, w1, b1, relu=True)
         h = PF.linear(h, w2, b2, relu=True)
         out = PF.linear(h, wh, bh)
-        n, so = self.num_priors, self.n_offsets
-        out = out.reshape(1, n, -1)
-        return self._update(priors, out[..., 0:2], out[..., 2:6], out[..., 6:6 + so])
+        return PF.lane_update(priors, out.reshape(1, self.num_priors, -1), self.prior_ys, self.img_w, self.img_h)
 
     def forward_first(self, decode_feat_l, priors):
         return self._branch(decode_feat_l, priors, False)

@@ -40,9 +40,11 @@ def test_argument_validation_needs_no_gpu(built):
     assert lib.phnet_lane_nms(None, None, None, 0, 10, 36, 50.0, 4, None, None, None, None) == 0      # zero frames: no-op
     assert lib.phnet_conv2d_fwd(None, None, None, None, 1, 8, 8, 3, 64, 3, 3, 1, 1, 0, None, 0, None) == -1   # Ci % 4
     assert lib.phnet_roi_pool_fwd(None, None, None, None, None, 1, 240, 36, 10, 25, 32, None) == -1   # C != 64
-    bm, bn, sp = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
-    assert lib.phnet_conv2d_plan(80000, 64, 576, 0, ctypes.byref(bm), ctypes.byref(bn), ctypes.byref(sp)) == 0
-    assert (bm.value, bn.value, sp.value) == (128, 64, 1)
+    bm, bn, sp, kt = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+    assert lib.phnet_conv2d_plan(80000, 64, 576, 0, ctypes.byref(bm), ctypes.byref(bn), ctypes.byref(sp), ctypes.byref(kt)) == 0
+    assert (bm.value, bn.value, sp.value, kt.value) == (128, 64, 1, 16)
+    assert lib.phnet_conv2d_plan(240, 64, 128, 0, ctypes.byref(bm), ctypes.byref(bn), ctypes.byref(sp), ctypes.byref(kt)) == 0
+    assert kt.value == 64
 
 
 @pytest.mark.parametrize("arch", ["resnet18", "resnet34"])
