@@ -1,0 +1,334 @@
+// Fused depth-wise stack of the adaptive routing gate for gfx950: LayerNorm([C,P]) followed by four residual blocks
+//   relu( LN(dw3x3( relu(LN(dw3x3(x))) )) + x )
+// as ONE forward launch and ONE backward launch (+ one reduce launch for the shared LayerNorm affine gradients).
+// The ATen formulation is 9 LayerNorm + 8 grouped-conv launches forward and ~50 backward per call, 15 calls per clip.
+//
+// Replaces libs/models/Router.py:72-75 (pre_norm + DWNets loop) forward and autograd backward; the Linear->ReLU->
+// Linear->ReLU->sigmoid tail (Router.py:76-80) stays on the GEMM kernels.
+// One workgroup per anchor: its (C x P) plane (2304 floats) lives in registers (9 per thread) and two LDS planes
+// (the depth-wise filter reads neighbours from LDS); every anchor has its own 3x3 filters (groups = N), the LayerNorm
+// affine parameters are shared by all anchors (-> per-anchor partial gradients + column reduce, deterministic).
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int EPT = 12;                     // elements per thread: planes up to 3072 floats
+constexpr int NPARAM = 34;                  // ln0_w, ln0_b, then per block: c1_w c1_b ln1_w ln1_b c2_w c2_b ln2_w ln2_b
+
+struct GateParams { const float* p[NPARAM]; };
+struct GateGrads { float* p[NPARAM]; };
+
+__device__ __forceinline__ void block_sum2(float& a, float& b, float* red) {
+    a = wave_sum(a); b = wave_sum(b);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = a; red[4 + (threadIdx.x >> 6)] = b; }
+    __syncthreads();
+    a = (red[0] + red[1]) + (red[2] + red[3]);
+    b = (red[4] + red[5]) + (red[6] + red[7]);
+}
+
+// LayerNorm statistics of the per-thread values v[] (elements idx < CP)
+__device__ __forceinline__ void plane_stats(const float (&v)[EPT], int CP, float eps, float& mu, float& rs, float* red) {
+    float s = 0.f, dummy = 0.f;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) s += (threadIdx.x + k * NT < CP) ? v[k] : 0.f;
+    block_sum2(s, dummy, red);
+    mu = s / (float)CP;
+    float q = 0.f; dummy = 0.f;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) { const float d = (threadIdx.x + k * NT < CP) ? v[k] - mu : 0.f; q += d * d; }
+    block_sum2(q, dummy, red);
+    rs = 1.0f / sqrtf(q / (float)CP + eps);
+}
+
+// out[k] = bias + sum_taps f[tap] * plane(c+di-1, p+dj-1)   (zero padding); flip -> 180-degree rotated filter
+__device__ __forceinline__ void dwconv_plane(const float* plane, const float* f9, float bias, int C, int P, int CP, bool flip,
+                                             float (&out)[EPT]) {
+    float f[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) f[t] = f9[flip ? 8 - t : t];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        const int i = threadIdx.x + k * NT;
+        float acc = bias;
+        if (i < CP) {
+            const int c = i / P, p = i - c * P;
+#pragma unroll
+            for (int di = 0; di < 3; ++di) {
+                const int cc = c + di - 1;
+                if (cc < 0 || cc >= C) continue;
+#pragma unroll
+                for (int dj = 0; dj < 3; ++dj) {
+                    const int pp = p + dj - 1;
+                    if (pp < 0 || pp >= P) continue;
+                    acc += f[di * 3 + dj] * plane[cc * P + pp];
+                }
+            }
+        }
+        out[k] = acc;
+    }
+}
+
+__device__ __forceinline__ void load_plane(const float* src, int CP, float (&v)[EPT]) {
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) { const int i = threadIdx.x + k * NT; v[k] = i < CP ? src[i] : 0.f; }
+}
+__device__ __forceinline__ void store_plane(float* dst, int CP, const float (&v)[EPT]) {
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) { const int i = threadIdx.x + k * NT; if (i < CP) dst[i] = v[k]; }
+}
+
+// planes: [13][N][CP] = s0..s3 | u0..u3 | t0..t3 | (12 unused)   stats: [N][18] = (mu, rs) of LN0, then per block LN1, LN2
+__global__ __launch_bounds__(NT) void gate_stack_fwd_kernel(const float* __restrict__ x, GateParams w, float* __restrict__ out,
+                                                            float* __restrict__ planes, float* __restrict__ stats,
+                                                            int N, int C, int P, float eps)
+{
+    extern __shared__ float lds[];                  // 2 planes
+    __shared__ float red[8];
+    const int n = blockIdx.x, CP = C * P;
+    float* P0 = lds;
+    float* P1 = lds + CP;
+    const size_t plane_off = (size_t)n * CP, slab = (size_t)N * CP;
+    float s[EPT], a[EPT];
+    load_plane(x + plane_off, CP, s);
+    float mu, rs;
+    plane_stats(s, CP, eps, mu, rs, red);
+    if (stats && threadIdx.x == 0) { stats[n * 18 + 0] = mu; stats[n * 18 + 1] = rs; }
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        const int i = threadIdx.x + k * NT;
+        if (i < CP) s[k] = (s[k] - mu) * rs * w.p[0][i] + w.p[1][i];
+    }
+    for (int b = 0; b < 4; ++b) {
+        const float* const* q = w.p + 2 + 8 * b;
+        if (planes) store_plane(planes + (size_t)b * slab + plane_off, CP, s);            // s_b
+        store_plane(P0, CP, s);
+        __syncthreads();
+        dwconv_plane(P0, q[0] + n * 9, q[1][n], C, P, CP, false, a);                       // u_b
+        if (planes) store_plane(planes + (size_t)(4 + b) * slab + plane_off, CP, a);
+        plane_stats(a, CP, eps, mu, rs, red);
+        if (stats && threadIdx.x == 0) { stats[n * 18 + 2 + 4 * b] = mu; stats[n * 18 + 3 + 4 * b] = rs; }
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            const int i = threadIdx.x + k * NT;
+            if (i < CP) a[k] = fmaxf((a[k] - mu) * rs * q[2][i] + q[3][i], 0.f);           // v_b
+        }
+        store_plane(P1, CP, a);
+        __syncthreads();
+        dwconv_plane(P1, q[4] + n * 9, q[5][n], C, P, CP, false, a);                       // t_b
+        if (planes) store_plane(planes + (size_t)(8 + b) * slab + plane_off, CP, a);
+        plane_stats(a, CP, eps, mu, rs, red);
+        if (stats && threadIdx.x == 0) { stats[n * 18 + 4 + 4 * b] = mu; stats[n * 18 + 5 + 4 * b] = rs; }
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            const int i = threadIdx.x + k * NT;
+            if (i < CP) s[k] = fmaxf((a[k] - mu) * rs * q[6][i] + q[7][i] + s[k], 0.f);    // s_{b+1}
+        }
+        __syncthreads();                            // everyone is done reading P0/P1 before the next block overwrites
+    }
+    store_plane(out + plane_off, CP, s);
+}
+
+// block-reduce the 10 depth-wise filter gradient partials (9 taps + bias) and write / accumulate them
+__device__ __forceinline__ void reduce_filter_grad(float (&acc)[10], float* red10, float* dw, float* db, int accumulate) {
+#pragma unroll
+    for (int t = 0; t < 10; ++t) acc[t] = wave_sum(acc[t]);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int t = 0; t < 10; ++t) red10[t * 4 + (threadIdx.x >> 6)] = acc[t];
+    __syncthreads();
+    if (threadIdx.x < 10) {
+        const float v = (red10[threadIdx.x * 4] + red10[threadIdx.x * 4 + 1]) + (red10[threadIdx.x * 4 + 2] + red10[threadIdx.x * 4 + 3]);
+        float* dst = threadIdx.x < 9 ? dw + threadIdx.x : db;
+        *dst = accumulate ? *dst + v : v;
+    }
+}
+
+// acc[tap] += g(c,p) * src(c+di-1, p+dj-1), acc[9] += g
+__device__ __forceinline__ void filter_grad_partials(const float* src_plane, const float (&g)[EPT], int C, int P, int CP,
+                                                     float (&acc)[10]) {
+#pragma unroll
+    for (int t = 0; t < 10; ++t) acc[t] = 0.f;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        const int i = threadIdx.x + k * NT;
+        if (i >= CP) continue;
+        const int c = i / P, p = i - c * P;
+        acc[9] += g[k];
+#pragma unroll
+        for (int di = 0; di < 3; ++di) {
+            const int cc = c + di - 1;
+            if (cc < 0 || cc >= C) continue;
+#pragma unroll
+            for (int dj = 0; dj < 3; ++dj) {
+                const int pp = p + dj - 1;
+                if (pp < 0 || pp >= P) continue;
+                acc[di * 3 + dj] += g[k] * src_plane[cc * P + pp];
+            }
+        }
+    }
+}
+
+// LayerNorm backward on register planes: g = upstream (already masked), xin = LN input; writes the affine partials
+// (g*xhat, g) to lnpart and returns dx in g.
+__device__ __forceinline__ void ln_backward(float (&g)[EPT], const float (&xin)[EPT], float mu, float rs, const float* gamma,
+                                            float* part_w, float* part_b, int CP, float* red) {
+    float xh[EPT];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        const int i = threadIdx.x + k * NT;
+        xh[k] = 0.f;
+        if (i < CP) {
+            xh[k] = (xin[k] - mu) * rs;
+            part_w[i] = g[k] * xh[k];
+            part_b[i] = g[k];
+            const float gw = g[k] * gamma[i];
+            g[k] = gw;
+            s1 += gw;
+            s2 += gw * xh[k];
+        }
+    }
+    block_sum2(s1, s2, red);
+    s1 /= (float)CP; s2 /= (float)CP;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) g[k] = rs * (g[k] - s1 - xh[k] * s2);
+}
+
+// lnpart: [N][18][CP] per-anchor partial gradients of the 9 LayerNorms' (weight, bias)
+__global__ __launch_bounds__(NT) void gate_stack_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ x,
+                                                            const float* __restrict__ out, GateParams w,
+                                                            const float* __restrict__ planes, const float* __restrict__ stats,
+                                                            GateGrads dg, float* __restrict__ lnpart,
+                                                            int N, int C, int P, float eps, int accumulate)
+{
+    extern __shared__ float lds[];                  // 2 planes
+    __shared__ float red[8], red10[40];
+    const int n = blockIdx.x, CP = C * P;
+    float* P0 = lds;
+    float* P1 = lds + CP;
+    const size_t plane_off = (size_t)n * CP, slab = (size_t)N * CP;
+    float* lp = lnpart + (size_t)n * 18 * CP;
+    float g[EPT], a[EPT], v[EPT], acc[10];
+    load_plane(gout + plane_off, CP, g);
+    for (int b = 3; b >= 0; --b) {
+        const float* const* q = w.p + 2 + 8 * b;
+        float* const* dq = dg.p + 2 + 8 * b;
+        // ---- relu of the block output, then LN2 backward (input t_b) ----
+        load_plane(b == 3 ? out + plane_off : planes + (size_t)(b + 1) * slab + plane_off, CP, a);
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) g[k] = a[k] > 0.f ? g[k] : 0.f;
+        float gres[EPT];
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) gres[k] = g[k];
+        load_plane(planes + (size_t)(8 + b) * slab + plane_off, CP, a);                        // t_b
+        ln_backward(g, a, stats[n * 18 + 4 + 4 * b], stats[n * 18 + 5 + 4 * b], q[6], lp + (size_t)(2 + 4 * b + 2) * CP,
+                    lp + (size_t)(2 + 4 * b + 3) * CP, CP, red);                               // g = dt
+        // ---- conv2 backward: needs v_b = relu(LN1(u_b)) and dt as planes ----
+        load_plane(planes + (size_t)(4 + b) * slab + plane_off, CP, a);                        // u_b
+        {
+            const float mu = stats[n * 18 + 2 + 4 * b], rs = stats[n * 18 + 3 + 4 * b];
+#pragma unroll
+            for (int k = 0; k < EPT; ++k) {
+                const int i = threadIdx.x + k * NT;
+                v[k] = i < CP ? fmaxf((a[k] - mu) * rs * q[2][i] + q[3][i], 0.f) : 0.f;
+            }
+        }
+        __syncthreads();
+        store_plane(P0, CP, v);
+        store_plane(P1, CP, g);
+        __syncthreads();
+        filter_grad_partials(P0, g, C, P, CP, acc);
+        reduce_filter_grad(acc, red10, dq[4] + n * 9, dq[5] + n, accumulate);
+        float dv[EPT];
+        dwconv_plane(P1, q[4] + n * 9, 0.f, C, P, CP, true, dv);
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) g[k] = v[k] > 0.f ? dv[k] : 0.f;                         // through the inner relu
+        // ---- LN1 backward (input u_b, still in a[]) ----
+        ln_backward(g, a, stats[n * 18 + 2 + 4 * b], stats[n * 18 + 3 + 4 * b], q[2], lp + (size_t)(2 + 4 * b + 0) * CP,
+                    lp + (size_t)(2 + 4 * b + 1) * CP, CP, red);                               // g = du
+        // ---- conv1 backward: input s_b ----
+        load_plane(planes + (size_t)b * slab + plane_off, CP, a);                              // s_b
+        __syncthreads();
+        store_plane(P0, CP, a);
+        store_plane(P1, CP, g);
+        __syncthreads();
+        filter_grad_partials(P0, g, C, P, CP, acc);
+        reduce_filter_grad(acc, red10, dq[0] + n * 9, dq[1] + n, accumulate);
+        dwconv_plane(P1, q[0] + n * 9, 0.f, C, P, CP, true, dv);
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) g[k] = dv[k] + gres[k];                                  // + residual path
+    }
+    // ---- pre-norm: only its affine gradients are needed (the gate input is detached, Router4OL.py:275) ----
+    load_plane(x + plane_off, CP, a);
+    {
+        const float mu = stats[n * 18 + 0], rs = stats[n * 18 + 1];
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            const int i = threadIdx.x + k * NT;
+            if (i < CP) { lp[i] = g[k] * ((a[k] - mu) * rs); lp[CP + i] = g[k]; }
+        }
+    }
+}
+
+// dst_j[i] (+)= sum_n lnpart[n][j][i]   for the 18 LayerNorm parameter tensors
+__global__ __launch_bounds__(NT) void gate_ln_grad_reduce_kernel(const float* __restrict__ lnpart, GateGrads dg, int N, int CP,
+                                                                 int accumulate)
+{
+    const long col = (long)blockIdx.x * NT + threadIdx.x;
+    if (col >= 18L * CP) return;
+    const int j = (int)(col / CP), i = (int)(col - (long)j * CP);
+    double s = 0.0;
+    for (int n = 0; n < N; ++n) s += (double)lnpart[((size_t)n * 18 + j) * CP + i];
+    // parameter slot of LayerNorm j: 0,1 -> ln0 (w,b); then block b: ln1 (w,b) at 2+8b+2, ln2 (w,b) at 2+8b+6
+    int slot;
+    if (j < 2) slot = j;
+    else { const int b = (j - 2) / 4, r = (j - 2) % 4; slot = 2 + 8 * b + (r < 2 ? 2 + r : 6 + (r - 2)); }
+    float* dst = dg.p[slot] + i;
+    *dst = accumulate ? *dst + (float)s : (float)s;
+}
+
+bool gate_args_ok(int N, int C, int P) { return N >= 1 && C >= 1 && P >= 1 && (long)C * P <= (long)NT * EPT; }
+
+}  // namespace
+
+PHNET_API uint64_t phnet_gate_stack_saved_floats(int32_t N, int32_t C, int32_t P) { return (uint64_t)12 * N * C * P + (uint64_t)18 * N; }
+PHNET_API uint64_t phnet_gate_stack_bwd_workspace(int32_t N, int32_t C, int32_t P) { return (uint64_t)18 * N * C * P * sizeof(float); }
+
+// x [N][C][P] gate input; params: HOST array of 34 device pointers in the order
+//   pre_norm.weight, pre_norm.bias, then for block 0..3: conv1.weight [N][9], conv1.bias [N], ln1.weight [C*P], ln1.bias,
+//   conv2.weight, conv2.bias, ln2.weight, ln2.bias.
+// out [N][C][P]; saved (training, may be NULL): phnet_gate_stack_saved_floats floats = 12 planes [N][C][P] + stats [N][18].
+PHNET_API int phnet_gate_stack_fwd(const float* x, const float* const* params, float* out, float* saved,
+                                   int32_t N, int32_t C, int32_t P, float eps, void* stream)
+{
+    if (!gate_args_ok(N, C, P) || !x || !params || !out) return PHNET_ERR_ARG;
+    GateParams w;
+    for (int i = 0; i < NPARAM; ++i) { w.p[i] = params[i]; if (!params[i]) return PHNET_ERR_ARG; }
+    const size_t CP = (size_t)C * P;
+    float* stats = saved ? saved + (size_t)12 * N * CP : nullptr;
+    hipLaunchKernelGGL(gate_stack_fwd_kernel, dim3(N), dim3(NT), 2 * CP * sizeof(float), (hipStream_t)stream,
+                       x, w, out, saved, stats, N, C, P, eps);
+    return phnet_launch_status();
+}
+
+// gout [N][C][P] = d loss / d out.  grads: HOST array of 34 device pointers (same order as params) that are
+// overwritten (accumulate=0) or added to (accumulate=1).  workspace >= phnet_gate_stack_bwd_workspace bytes.
+PHNET_API int phnet_gate_stack_bwd(const float* gout, const float* x, const float* out, const float* const* params,
+                                   const float* saved, float* const* grads, int32_t N, int32_t C, int32_t P, float eps,
+                                   int32_t accumulate, void* workspace, uint64_t ws_bytes, void* stream)
+{
+    if (!gate_args_ok(N, C, P) || !gout || !x || !out || !params || !saved || !grads || !workspace) return PHNET_ERR_ARG;
+    const size_t CP = (size_t)C * P;
+    if ((uint64_t)18 * N * CP * sizeof(float) > ws_bytes) return PHNET_ERR_WORKSPACE;
+    GateParams w; GateGrads dg;
+    for (int i = 0; i < NPARAM; ++i) { w.p[i] = params[i]; dg.p[i] = grads[i]; if (!params[i] || !grads[i]) return PHNET_ERR_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(gate_stack_bwd_kernel, dim3(N), dim3(NT), 2 * CP * sizeof(float), st,
+                       gout, x, out, w, saved, saved + (size_t)12 * N * CP, dg, (float*)workspace, N, C, P, eps, accumulate);
+    hipLaunchKernelGGL(gate_ln_grad_reduce_kernel, dim3((unsigned)ceil_div64(18L * CP, NT)), dim3(NT), 0, st,
+                       (const float*)workspace, dg, N, (int)CP, accumulate);
+    return phnet_launch_status();
+}

@@ -138,6 +138,38 @@ def roi_pool(fmap, xs, ys):
     return _RoiPool.apply(fmap, xs, ys)
 
 
+class _GateStack(torch.autograd.Function):
+    """Gate depth-wise stack (pre_norm + 4 residual dw blocks) as one fused launch each way.  The input is the detached
+    ROI copy (no input gradient, Router4OL.py:275); parameter gradients are accumulated straight into the gradient
+    arena when every parameter is arena-backed, otherwise returned to autograd."""
+
+    @staticmethod
+    def forward(ctx, x, eps, *params):
+        xc = x.contiguous()
+        pc = [p.contiguous() for p in params]
+        need = any(ctx.needs_input_grad[2:])          # (grad mode is off inside forward; ask autograd instead)
+        out, saved = K.gate_stack_fwd(xc, pc, eps, need)
+        ctx.eps = eps
+        ctx.direct = [direct_grad(p) for p in params]
+        ctx.pshapes = [p.shape for p in params]
+        ctx.save_for_backward(xc, out, saved, *pc)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        xc, out, saved, *pc = ctx.saved_tensors
+        if all(d is not None for d in ctx.direct):
+            K.gate_stack_bwd(gout.contiguous(), xc, out, pc, saved, ctx.direct, ctx.eps, True)
+            return (None, None) + (None,) * len(pc)
+        grads = [torch.empty_like(p) for p in pc]
+        K.gate_stack_bwd(gout.contiguous(), xc, out, pc, saved, grads, ctx.eps, False)
+        return (None, None) + tuple(g.view(s) for g, s in zip(grads, ctx.pshapes))
+
+
+def gate_stack(x, params, eps: float = 1e-5):
+    return _GateStack.apply(x, eps, *params)
+
+
 class _LaneUpdate(torch.autograd.Function):
     """(priors [1,N,6+S], head [1,N,HW]) -> (preds, lines): prior update of both branches in one launch each way."""
 

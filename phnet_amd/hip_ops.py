@@ -457,3 +457,27 @@ def lane_update_bwd(dpreds, dlines, lines, head, ys, img_w, img_h, need_dpriors:
     check(lib().phnet_lane_update_bwd(_ptr(dpreds), _ptr(dlines), _ptr(lines), _ptr(head), _ptr(ys), _ptr(dhead), _ptr(dpriors),
                                       n, w - 6, head.shape[1], float(img_w), float(img_h), _stream()), "phnet_lane_update_bwd")
     return dhead, dpriors
+
+
+def _ptr_array(tensors):
+    import ctypes
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def gate_stack_fwd(x, params, eps: float, save: bool):
+    """x [N,C,P]; params: the 34 tensors in the C-ABI order.  Returns (out, saved or None)."""
+    _req(x, name="x")
+    n, c, p = x.shape
+    out = torch.empty_like(x)
+    saved = torch.empty(lib().phnet_gate_stack_saved_floats(n, c, p), dtype=torch.float32, device=x.device) if save else None
+    check(lib().phnet_gate_stack_fwd(_ptr(x), _ptr_array(params), _ptr(out), _ptr(saved), n, c, p, eps, _stream()),
+          "phnet_gate_stack_fwd")
+    return out, saved
+
+
+def gate_stack_bwd(gout, x, out, params, saved, grads, eps: float, accumulate: bool):
+    _req(gout, name="gout")
+    n, c, p = x.shape
+    ws = workspace(lib().phnet_gate_stack_bwd_workspace(n, c, p), x.device, 3)
+    check(lib().phnet_gate_stack_bwd(_ptr(gout), _ptr(x), _ptr(out), _ptr_array(params), _ptr(saved), _ptr_array(grads),
+                                     n, c, p, eps, int(accumulate), _ptr(ws), ws.numel(), _stream()), "phnet_gate_stack_bwd")

@@ -32,12 +32,10 @@ class AdaptiveRouter4Lane(nn.Module):
         b, n, c, p = xs.shape
         assert b == 1
         pn = self.pre_norm[stage]
-        x = PF.layer_norm(xs.reshape(n, c, p), pn.weight, pn.bias, eps=pn.eps)
+        params = [pn.weight, pn.bias]
         for blk in self.DWNets[stage]:
-            y = PF.dwconv3x3(x, blk[0].weight, blk[0].bias)
-            y = PF.layer_norm(y, blk[1].weight, blk[1].bias, relu=True, eps=blk[1].eps)
-            y = PF.dwconv3x3(y, blk[3].weight, blk[3].bias)
-            x = PF.layer_norm(y, blk[4].weight, blk[4].bias, res=x, relu=True, eps=blk[4].eps)
+            params += [blk[0].weight, blk[0].bias, blk[1].weight, blk[1].bias, blk[3].weight, blk[3].bias, blk[4].weight, blk[4].bias]
+        x = PF.gate_stack(xs.reshape(n, c, p), params, eps=pn.eps)        # one fused launch (csrc/gate.hip)
         mlp = self.layers[stage]
         h = PF.linear(x.reshape(n, c * p), mlp[0].weight, mlp[0].bias, relu=True)
         h = PF.linear(h, mlp[2].weight, mlp[2].bias, relu=True)          # ReLU before the sigmoid (Router.py:45-48)
