@@ -12,8 +12,9 @@
 
 namespace {
 
-constexpr int NT = 256;
-constexpr int EPT = 12;                     // elements per thread: planes up to 3072 floats
+constexpr int NT = 1024;                    // 16 wavefronts per anchor: the chain is latency-bound, more waves hide it
+constexpr int NW = NT / 64;
+constexpr int EPT = 3;                      // elements per thread: planes up to 3072 floats
 constexpr int NPARAM = 34;                  // ln0_w, ln0_b, then per block: c1_w c1_b ln1_w ln1_b c2_w c2_b ln2_w ln2_b
 
 struct GateParams { const float* p[NPARAM]; };
@@ -22,10 +23,12 @@ struct GateGrads { float* p[NPARAM]; };
 __device__ __forceinline__ void block_sum2(float& a, float& b, float* red) {
     a = wave_sum(a); b = wave_sum(b);
     __syncthreads();
-    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = a; red[4 + (threadIdx.x >> 6)] = b; }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = a; red[NW + (threadIdx.x >> 6)] = b; }
     __syncthreads();
-    a = (red[0] + red[1]) + (red[2] + red[3]);
-    b = (red[4] + red[5]) + (red[6] + red[7]);
+    float sa = 0.f, sb = 0.f;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) { sa += red[k]; sb += red[NW + k]; }
+    a = sa; b = sb;
 }
 
 // LayerNorm statistics of the per-thread values v[] (elements idx < CP)
@@ -85,7 +88,7 @@ __global__ __launch_bounds__(NT) void gate_stack_fwd_kernel(const float* __restr
                                                             int N, int C, int P, float eps)
 {
     extern __shared__ float lds[];                  // 2 planes
-    __shared__ float red[8];
+    __shared__ float red[2 * NW];
     const int n = blockIdx.x, CP = C * P;
     float* P0 = lds;
     float* P1 = lds + CP;
@@ -137,10 +140,12 @@ __device__ __forceinline__ void reduce_filter_grad(float (&acc)[10], float* red1
     __syncthreads();
     if ((threadIdx.x & 63) == 0)
 #pragma unroll
-        for (int t = 0; t < 10; ++t) red10[t * 4 + (threadIdx.x >> 6)] = acc[t];
+        for (int t = 0; t < 10; ++t) red10[t * NW + (threadIdx.x >> 6)] = acc[t];
     __syncthreads();
     if (threadIdx.x < 10) {
-        const float v = (red10[threadIdx.x * 4] + red10[threadIdx.x * 4 + 1]) + (red10[threadIdx.x * 4 + 2] + red10[threadIdx.x * 4 + 3]);
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) v += red10[threadIdx.x * NW + k];
         float* dst = threadIdx.x < 9 ? dw + threadIdx.x : db;
         *dst = accumulate ? *dst + v : v;
     }
@@ -205,7 +210,7 @@ __global__ __launch_bounds__(NT) void gate_stack_bwd_kernel(const float* __restr
                                                             int N, int C, int P, float eps, int accumulate)
 {
     extern __shared__ float lds[];                  // 2 planes
-    __shared__ float red[8], red10[40];
+    __shared__ float red[2 * NW], red10[10 * NW];
     const int n = blockIdx.x, CP = C * P;
     float* P0 = lds;
     float* P1 = lds + CP;
@@ -274,10 +279,10 @@ __global__ __launch_bounds__(NT) void gate_stack_bwd_kernel(const float* __restr
 }
 
 // dst_j[i] (+)= sum_n lnpart[n][j][i]   for the 18 LayerNorm parameter tensors
-__global__ __launch_bounds__(NT) void gate_ln_grad_reduce_kernel(const float* __restrict__ lnpart, GateGrads dg, int N, int CP,
-                                                                 int accumulate)
+__global__ __launch_bounds__(256) void gate_ln_grad_reduce_kernel(const float* __restrict__ lnpart, GateGrads dg, int N, int CP,
+                                                                  int accumulate)
 {
-    const long col = (long)blockIdx.x * NT + threadIdx.x;
+    const long col = (long)blockIdx.x * 256 + threadIdx.x;
     if (col >= 18L * CP) return;
     const int j = (int)(col / CP), i = (int)(col - (long)j * CP);
     double s = 0.0;
@@ -328,7 +333,7 @@ PHNET_API int phnet_gate_stack_bwd(const float* gout, const float* x, const floa
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(gate_stack_bwd_kernel, dim3(N), dim3(NT), 2 * CP * sizeof(float), st,
                        gout, x, out, w, saved, saved + (size_t)12 * N * CP, dg, (float*)workspace, N, C, P, eps, accumulate);
-    hipLaunchKernelGGL(gate_ln_grad_reduce_kernel, dim3((unsigned)ceil_div64(18L * CP, NT)), dim3(NT), 0, st,
+    hipLaunchKernelGGL(gate_ln_grad_reduce_kernel, dim3((unsigned)ceil_div64(18L * CP, 256)), dim3(256), 0, st,
                        (const float*)workspace, dg, N, (int)CP, accumulate);
     return phnet_launch_status();
 }
