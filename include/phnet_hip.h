@@ -70,7 +70,8 @@ int phnet_conv2d_plan(int64_t M, int32_t Co, int32_t K, uint64_t ws_bytes, int32
 int phnet_tune_force_conv_tile(int32_t bm, int32_t bn, int32_t splits);
 uint64_t phnet_conv2d_wgrad_workspace(int32_t N, int32_t Hi, int32_t Wi, int32_t Ci, int32_t Co,
                                       int32_t R, int32_t S, int32_t stride, int32_t pad);
-int phnet_conv2d_wgrad(const float* dy, const float* x, float* dw,
+/* dbias (optional, [Co]) = sum of dy over all pixels = the bias gradient, produced by the same launch. */
+int phnet_conv2d_wgrad(const float* dy, const float* x, float* dw, float* dbias,
                        int32_t N, int32_t Hi, int32_t Wi, int32_t Ci, int32_t Co, int32_t R, int32_t S,
                        int32_t stride, int32_t pad, int32_t accumulate, void* workspace, uint64_t ws_bytes, void* stream);
 /* stem helpers: NCHW 3-channel frames -> NHWC padded to 4 channels; innermost-dimension pad/truncate. */

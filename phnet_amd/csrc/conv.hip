@@ -250,9 +250,12 @@ struct WgradShape {
     int splits, pix_per_split;   // multiple of BK
 };
 
+// out: dW itself when g.splits == 1 (written or accumulated in the epilogue) else the split-K partial buffer
+// [splits][Co*NC + Co] (the trailing Co floats of every split hold its bias-gradient partial).
 template <int BM, int BN>
 __global__ __launch_bounds__(THREADS) void conv_wgrad_kernel(
-    const float* __restrict__ dY, const float* __restrict__ X, float* __restrict__ out, WgradShape g)
+    const float* __restrict__ dY, const float* __restrict__ X, float* __restrict__ out, float* __restrict__ dbias,
+    WgradShape g, int want_bias, int accumulate)
 {
     constexpr int TM = BM / 2, TN = BN / 2, FM = TM / 32, FN = TN / 32;
     constexpr int A_PITCH = KStridedTile<BM, BK>::PITCH, B_PITCH = KStridedTile<BN, BK>::PITCH;
@@ -305,7 +308,10 @@ __global__ __launch_bounds__(THREADS) void conv_wgrad_kernel(
         a_ch[i] = (idx - a_kk[i] * (BM / 4)) * 4;
     }
 
-    f32x4 a_reg[A_LOADS], b_reg[B_LOADS];
+    f32x4 a_reg[A_LOADS], b_reg[B_LOADS], bsum[A_LOADS];
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) bsum[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool bias_block = want_bias && n0 == 0;            // the first column tile also sums dY over the pixels
     // loads the K step that starts at pixel pt; MUST be called with pt = p_begin, p_begin+BK, ... in order
     auto load_global = [&](int pt) {
 #pragma unroll
@@ -313,6 +319,7 @@ __global__ __launch_bounds__(THREADS) void conv_wgrad_kernel(
             const int p = pt + a_kk[i], co = m0 + a_ch[i];
             a_reg[i] = (p < p_end && co < g.Co) ? *reinterpret_cast<const f32x4*>(dY + (size_t)p * g.Co + co)
                                                 : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (bias_block) bsum[i] += a_reg[i];
         }
 #pragma unroll
         for (int i = 0; i < B_LOADS; ++i) {
@@ -362,7 +369,8 @@ __global__ __launch_bounds__(THREADS) void conv_wgrad_kernel(
             buf ^= 1;
         }
     }
-    float* dst = out + (size_t)blockIdx.z * g.Co * NC;
+    const bool direct = g.splits == 1;
+    float* dst = direct ? out : out + (size_t)blockIdx.z * ((size_t)g.Co * NC + g.Co);
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
         const int n = n0 + wn + j * 32 + frag_col(lane);
@@ -372,9 +380,41 @@ __global__ __launch_bounds__(THREADS) void conv_wgrad_kernel(
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int m = m0 + wm + i * 32 + frag_row(lane, e);
-                if (m < g.Co) dst[(size_t)m * NC + n] = acc[i][j][e];
+                if (m < g.Co) {
+                    float* q = dst + (size_t)m * NC + n;
+                    *q = (direct && accumulate) ? *q + acc[i][j][e] : acc[i][j][e];
+                }
             }
     }
+    if (bias_block) {
+        // per-thread sums cover rows a_kk of every K step; fold the BK rows through LDS (reusing the A image)
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i)
+            *reinterpret_cast<f32x4*>(As + a_kk[i] * A_PITCH + a_ch[i]) = bsum[i];
+        __syncthreads();
+        if (tid < BM && m0 + tid < g.Co) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < BK; ++k) t += As[k * A_PITCH + tid];
+            if (direct) dbias[m0 + tid] = accumulate ? dbias[m0 + tid] + t : t;
+            else dst[(size_t)g.Co * NC + m0 + tid] = t;
+        }
+    }
+}
+
+// dW (+)= sum_z part[z][0:nw],  dbias (+)= sum_z part[z][nw:nw+nb]   (part rows are nw+nb floats long)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                           float* __restrict__ dbias, long nw, long nb, int splits, int accumulate)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nw + nb) return;
+    const long stride = nw + nb;
+    float s = part[i];
+    for (int z = 1; z < splits; ++z) s += part[i + (long)z * stride];
+    float* dst = i < nw ? dw + i : dbias + (i - nw);
+    if (i >= nw && !dbias) return;
+    *dst = accumulate ? *dst + s : s;
 }
 
 // ---- stem helpers: NCHW (3 ch) -> NHWC padded to 4 channels; OHWI weight pad 3->4 and back -----------
@@ -569,10 +609,13 @@ PHNET_API uint64_t phnet_conv2d_wgrad_workspace(int32_t N, int32_t Hi, int32_t W
 {
     const long Ho = (Hi + 2 * pad - R) / stride + 1, Wo = (Wi + 2 * pad - S) / stride + 1;
     const long P = (long)N * Ho * Wo, NC = (long)R * S * Ci;
-    return (uint64_t)(wgrad_splits(P, Co, NC, nullptr) * Co * NC * sizeof(float));
+    return (uint64_t)(wgrad_splits(P, Co, NC, nullptr) * (Co * NC + Co) * sizeof(float));
 }
 
-PHNET_API int phnet_conv2d_wgrad(const float* dy, const float* x, float* dw,
+// dw OHWI [Co][R][S][Ci] and (optionally) dbias [Co] = sum of dy over all pixels are overwritten (accumulate=0) or
+// added to (accumulate=1).  workspace: phnet_conv2d_wgrad_workspace bytes (split-K partial sums; unused when the
+// problem runs unsplit).
+PHNET_API int phnet_conv2d_wgrad(const float* dy, const float* x, float* dw, float* dbias,
                                  int32_t N, int32_t Hi, int32_t Wi, int32_t Ci, int32_t Co, int32_t R, int32_t S,
                                  int32_t stride, int32_t pad, int32_t accumulate,
                                  void* workspace, uint64_t ws_bytes, void* stream)
@@ -590,18 +633,21 @@ PHNET_API int phnet_conv2d_wgrad(const float* dy, const float* x, float* dw,
     const int bn = 64;
     long splits = wgrad_splits(P, Co, NC, &bm);
     const long tiles = ceil_div64(Co, bm) * ceil_div64(NC, bn);
-    while (splits > 1 && (uint64_t)(splits * Co * NC * sizeof(float)) > ws_bytes) --splits;
-    if (!workspace || (uint64_t)(splits * Co * NC * sizeof(float)) > ws_bytes) return PHNET_ERR_WORKSPACE;
+    const long row = (long)Co * NC + Co;
+    while (splits > 1 && (!workspace || (uint64_t)(splits * row * sizeof(float)) > ws_bytes)) --splits;
     const long psteps = ceil_div64(max(P, (long)1), BK);
     g.splits = (int)splits;
     g.pix_per_split = (int)(ceil_div64(psteps, splits) * BK);
+    float* out = splits > 1 ? (float*)workspace : dw;
     dim3 grid((unsigned)tiles, 1, (unsigned)splits);
-    if (bm == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, 64>), grid, dim3(THREADS), 0, st, dy, x, (float*)workspace, g);
-    else hipLaunchKernelGGL((conv_wgrad_kernel<64, 64>), grid, dim3(THREADS), 0, st, dy, x, (float*)workspace, g);
-    const long total4 = (long)Co * NC / 4;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)ceil_div64(total4, 256)), dim3(256), 0, st,
-                       (const float*)workspace, dw, (const float*)nullptr, (const float*)nullptr, total4, (int)NC, (int)splits, 0,
-                       accumulate);
+    const int want_bias = dbias != nullptr;
+    if (bm == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, 64>), grid, dim3(THREADS), 0, st, dy, x, out, dbias, g, want_bias, accumulate);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<64, 64>), grid, dim3(THREADS), 0, st, dy, x, out, dbias, g, want_bias, accumulate);
+    if (splits > 1) {
+        const long nw = (long)Co * NC, nb = Co;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div64(nw + nb, 256)), dim3(256), 0, st,
+                           (const float*)workspace, dw, dbias, nw, nb, (int)splits, accumulate);
+    }
     return phnet_launch_status();
 }
 

@@ -42,12 +42,18 @@ class _Linear(torch.autograd.Function):
             g = K.relu_bwd(g, y)
         dx = K.linear_dgrad(g, w).view(ctx.xshape) if ctx.needs_input_grad[0] else None
         dw = db = None
+        want_b = ctx.has_b and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            if ctx.w_direct is not None:
-                K.linear_wgrad(g, x2, dw=ctx.w_direct, accumulate=True)
+            # weight and bias gradient come out of the same launch (the bias gradient is the column sum of g)
+            if ctx.w_direct is not None and (not want_b or ctx.b_direct is not None):
+                K.linear_wgrad(g, x2, dw=ctx.w_direct, accumulate=True, dbias=ctx.b_direct if want_b else None)
+                want_b = False
             else:
-                dw = K.linear_wgrad(g, x2)[:n]
-        if ctx.has_b and ctx.needs_input_grad[2]:
+                db_full = torch.empty(n4, dtype=torch.float32, device=g.device) if want_b else None
+                dw = K.linear_wgrad(g, x2, dbias=db_full)[:n]
+                if want_b:
+                    db, want_b = db_full[:n], False
+        if want_b:
             if ctx.b_direct is not None:
                 K.colsum(g, out=ctx.b_direct, accumulate=True)
             else:

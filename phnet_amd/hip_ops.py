@@ -151,17 +151,20 @@ def conv2d_dgrad(dy, w, in_hw: Tuple[int, int], stride: int, pad: int, addend: O
     return dx
 
 
-def conv2d_wgrad(dy, x, w_shape, stride: int, pad: int, dw: Optional[torch.Tensor] = None, accumulate: bool = False):
+def conv2d_wgrad(dy, x, w_shape, stride: int, pad: int, dw: Optional[torch.Tensor] = None, accumulate: bool = False,
+                 dbias: Optional[torch.Tensor] = None):
+    """dW (and, when `dbias` is given, the bias gradient = column sums of dy) in one launch (+ reduce when split).
+    `accumulate` applies to both destinations."""
     _req(dy, name="dy"); _req(x, name="x")
     n, hi, wi, ci = x.shape
     co, r, s, _ = w_shape
     if dw is None:
         dw = torch.empty((co, r, s, ci), dtype=torch.float32, device=x.device)
-        accumulate = False
+        assert not accumulate
     need = lib().phnet_conv2d_wgrad_workspace(n, hi, wi, ci, co, r, s, stride, pad)
     ws = workspace(need, x.device)
-    check(lib().phnet_conv2d_wgrad(_ptr(dy), _ptr(x), _ptr(dw), n, hi, wi, ci, co, r, s, stride, pad, int(accumulate),
-                                   _ptr(ws), ws.numel(), _stream()), "phnet_conv2d_wgrad")
+    check(lib().phnet_conv2d_wgrad(_ptr(dy), _ptr(x), _ptr(dw), _ptr(dbias), n, hi, wi, ci, co, r, s, stride, pad,
+                                   int(accumulate), _ptr(ws), ws.numel(), _stream()), "phnet_conv2d_wgrad")
     return dw
 
 
@@ -177,11 +180,11 @@ def linear_dgrad(dy2d, w):
     return conv2d_dgrad(dy2d.view(m, 1, 1, n), w.view(n, 1, 1, k), (1, 1), 1, 0).view(m, k)
 
 
-def linear_wgrad(dy2d, x2d, dw: Optional[torch.Tensor] = None, accumulate: bool = False):
+def linear_wgrad(dy2d, x2d, dw: Optional[torch.Tensor] = None, accumulate: bool = False, dbias: Optional[torch.Tensor] = None):
     m, n = dy2d.shape
     k = x2d.shape[1]
     out = conv2d_wgrad(dy2d.view(m, 1, 1, n), x2d.view(m, 1, 1, k), (n, 1, 1, k), 1, 0,
-                       None if dw is None else dw.view(n, 1, 1, k), accumulate)
+                       None if dw is None else dw.view(n, 1, 1, k), accumulate, dbias)
     return out.view(n, k)
 
 

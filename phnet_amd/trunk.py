@@ -108,12 +108,18 @@ class EncoderFunction(torch.autograd.Function):
             d = direct_grad(p)                    # arena view with the parameter's channels_last strides
             return None if d is None else d.permute(0, 2, 3, 1)
 
-        def conv_wgrad_into(p, dy, x, wshape, stride, pad):
+        def conv_wgrad_into(p, dy, x, wshape, stride, pad, bias=None):
+            """weight gradient (and the bias gradient of the FPN convs) from one launch; arena-backed destinations are
+            accumulated in place, otherwise the gradients go back through autograd."""
             d = dest_ohwi(p)
-            if d is not None and d.is_contiguous():
-                K.conv2d_wgrad(dy, x, wshape, stride, pad, dw=d, accumulate=True)
-            else:
-                put(p, oihw_grad(K.conv2d_wgrad(dy, x, wshape, stride, pad)))
+            db = direct_grad(bias) if bias is not None else None
+            if d is not None and d.is_contiguous() and (bias is None or db is not None):
+                K.conv2d_wgrad(dy, x, wshape, stride, pad, dw=d, accumulate=True, dbias=db)
+                return
+            dbt = torch.empty(wshape[0], dtype=torch.float32, device=dy.device) if bias is not None else None
+            put(p, oihw_grad(K.conv2d_wgrad(dy, x, wshape, stride, pad, dbias=dbt)))
+            if bias is not None:
+                put(bias, dbt)
 
         def bias_grad_into(p, dy):
             d = direct_grad(p)
@@ -127,16 +133,14 @@ class EncoderFunction(torch.autograd.Function):
         dl = []
         for i in range(3):
             m = neck.fpn_convs[i].conv
-            conv_wgrad_into(m.weight, douts[i], ctx.lats[i], ctx.out_w[i].shape, 1, 1)
-            bias_grad_into(m.bias, douts[i])
+            conv_wgrad_into(m.weight, douts[i], ctx.lats[i], ctx.out_w[i].shape, 1, 1, bias=m.bias)
             dl.append(K.conv2d_dgrad(douts[i], ctx.out_w[i], tuple(ctx.lats[i].shape[1:3]), 1, 1))
         for i in (1, 2):
             K.upsample_add_bwd_(dl[i - 1], dl[i])
         dstage = []
         for i in range(3):
             m = neck.lateral_convs[i].conv
-            conv_wgrad_into(m.weight, dl[i], ctx.feats[i], ctx.lat_w[i].shape, 1, 0)
-            bias_grad_into(m.bias, dl[i])
+            conv_wgrad_into(m.weight, dl[i], ctx.feats[i], ctx.lat_w[i].shape, 1, 0, bias=m.bias)
             dstage.append(K.conv2d_dgrad(dl[i], ctx.lat_w[i], tuple(ctx.feats[i].shape[1:3]), 1, 0))
         # ---- trunk, last block first ----------------------------------------------------------------------
         tape = ctx.tape

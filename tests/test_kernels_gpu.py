@@ -138,6 +138,12 @@ def test_conv_fwd_dgrad_wgrad(ops, case):
     close(dw, w.grad.permute(0, 2, 3, 1), 2e-5)
     dw2 = ops.conv2d_wgrad(gyd, xd, wd.shape, stride, pad, dw=dw.clone(), accumulate=True)
     close(dw2, 2 * w.grad.permute(0, 2, 3, 1), 2e-5)
+    db = torch.full((Co,), 7.0, device="cuda")                       # fused bias gradient = column sums of dy
+    dw3 = ops.conv2d_wgrad(gyd, xd, wd.shape, stride, pad, dbias=db)
+    close(dw3, w.grad.permute(0, 2, 3, 1), 2e-5)
+    close(db, gy.sum(dim=(0, 2, 3)), 2e-5)
+    ops.conv2d_wgrad(gyd, xd, wd.shape, stride, pad, dw=dw3, accumulate=True, dbias=db)
+    close(db, 2 * gy.sum(dim=(0, 2, 3)), 2e-5)
 
 
 def test_linear_wrappers(ops):
