@@ -291,6 +291,8 @@ class RouterOL(nn.Module):
             raise RuntimeError("phnet_amd runs on the GPU only: move the model and the clip to cuda")
         T = frame.shape[0]
         self.detNet._branch_cache = None                                       # weights may have changed since the last clip
+        for head in self.detNet.DHead_series:
+            head.begin_clip()
         feats = self.backbone(frame)                                           # 3 x [T,h,w,C] NHWC
         last_cuts = []
         total_loss = 0.0
@@ -314,6 +316,8 @@ class RouterOL(nn.Module):
                 if t >= self.save_freq_max:
                     last_cuts.pop(0)
         self.detNet._branch_cache = None
+        for head in self.detNet.DHead_series:
+            head.begin_clip()
         return total_loss if self.training else clip_outputs
 
     def _tokens(self, feat, rows):

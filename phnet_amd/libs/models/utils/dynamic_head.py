@@ -20,6 +20,25 @@ class DynamicConv(nn.Module):
         self.activation = nn.ReLU()
         self.out_layer = nn.Sequential(nn.Linear(c * feat_size, 6 * c), nn.Linear(6 * c, c))
         self.norm3 = nn.LayerNorm(c)
+        self._folded = None          # per-clip cache of folded Linear->Linear pairs (see _fold)
+
+    def begin_clip(self):
+        self._folded = None
+
+    def _fold(self, name: str, seq: nn.Sequential):
+        """A Linear->Linear pair with nothing in between (dynamic_head.py:16-17, 27-28) is one affine map:
+        y = x (W2 W1)^T + (W2 b1 + b2).  Folding it once per clip (the weights are constant inside a clip, the pair is
+        applied 5 times per clip) turns 2*M*K*H + 2*M*H*N FLOPs per call into 2*M*K*N - 16x fewer for
+        dynamic_layer_1 (K=64, H=1024, N=8192) - and the fold itself is an ordinary GEMM on the HIP kernels, so
+        autograd carries the gradients back to both original weight matrices.  Same result up to fp32 re-association."""
+        if self._folded is None:
+            self._folded = {}
+        if name not in self._folded:
+            l1, l2 = seq[0], seq[1]
+            w_eff_t = PF.linear(l1.weight.t().contiguous(), l2.weight)              # [K, N] = (W2 W1)^T
+            b_eff = PF.linear(l1.bias.unsqueeze(0), l2.weight, l2.bias)[0]          # W2 b1 + b2
+            self._folded[name] = (w_eff_t.t().contiguous(), b_eff.contiguous())
+        return self._folded[name]
 
     def forward(self, pro_feature: torch.Tensor, roi_feature: torch.Tensor) -> torch.Tensor:
         """pro_feature [B,N,C], roi_feature [B,N,P,C] -> [B,N,C]."""
@@ -27,12 +46,14 @@ class DynamicConv(nn.Module):
         roi = roi_feature.reshape(b * n, p, c)
         pro = pro_feature.reshape(b * n, c)
         l1, l2, lo = self.dynamic_layer_1, self.dynamic_layer_2, self.out_layer
-        w1 = PF.linear(PF.linear(pro, l1[0].weight, l1[0].bias), l1[1].weight, l1[1].bias).view(b * n, c, 2 * c)
+        we, be = self._fold("dynamic_layer_1", l1)
+        w1 = PF.linear(pro, we, be).view(b * n, c, 2 * c)
         f = PF.bmm(roi, w1)
         f = PF.layer_norm(f, self.norm1.weight, self.norm1.bias, relu=True, eps=self.norm1.eps)
         w2 = PF.linear(PF.linear(f.detach().reshape(b * n, -1), l2[0].weight, l2[0].bias), l2[1].weight, l2[1].bias)
         f = PF.bmm(f, w2.view(b * n, 2 * c, c))
         f = PF.layer_norm(f, self.norm2.weight, self.norm2.bias, relu=True, eps=self.norm2.eps)
-        f = PF.linear(PF.linear(f.reshape(b * n, -1), lo[0].weight, lo[0].bias), lo[1].weight, lo[1].bias)
+        wo, bo = self._fold("out_layer", lo)
+        f = PF.linear(f.reshape(b * n, -1), wo, bo)
         f = PF.layer_norm(f, self.norm3.weight, self.norm3.bias, eps=self.norm3.eps)
         return f.view(b, n, c)
