@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--cpu-clips", type=int, default=2)
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--eager", action="store_true", help="do not capture the step in a hipGraph (always eager for N>1)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL over xGMI; gloo only for "
+                                                      "functional rehearsals of the N>1 path on a single GPU)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
     return ap.parse_args()
 
 
@@ -80,8 +83,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", init_method="env://")
+        torch.cuda.set_device(0 if args.share_gpu else local_rank)
+        dist.init_process_group(backend=args.backend, init_method="env://")
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -105,7 +108,7 @@ def main():
     arena = GradArena(model.parameters())          # flat fp32 gradient buffer; HIP backward kernels accumulate into it
     decay = [p for p in model.parameters() if p.dim() > 1]
     no_decay = [p for p in model.parameters() if p.dim() <= 1]
-    use_graph = world == 1 and not args.eager
+    use_graph = not args.eager
     opt = torch.optim.AdamW([{"params": decay, "weight_decay": 5e-4}, {"params": no_decay, "weight_decay": 0.0}],
                             lr=5e-4, betas=(0.9, 0.999), fused=True, capturable=use_graph)
     T = args.frames
@@ -125,7 +128,8 @@ def main():
     if use_graph:
         from phnet_amd.graphed import GraphedTrainStep
         try:
-            graphed = GraphedTrainStep(model, opt, clips[0], lanes, loss_divisor=T, warmup=2, arena=arena)
+            between = (lambda: parallel.allreduce_flat_(arena.flat, chunks=4)) if world > 1 else None
+            graphed = GraphedTrainStep(model, opt, clips[0], lanes, loss_divisor=T, warmup=2, arena=arena, between=between)
             print("[bench] training step captured in a hipGraph", file=sys.stderr, flush=True)
         except Exception as e:                                       # noqa: BLE001
             print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr, flush=True)
@@ -196,7 +200,8 @@ def main():
                "config": {"workload": f"{T}-frame clip 3x{args.height}x{args.width}, {args.arch} + router + lane head, fwd+bwd+AdamW, "
                                       f"1 clip/GPU/step, random-init weights", "parallelism": f"dp{world}",
                           "timed_region": "grad-arena memset + forward + loss + backward (+ flat RCCL all-reduce when N>1) + AdamW step",
-                          "launch": "hipGraph replay of the whole step" if graphed is not None else "eager"},
+                          "launch": ("hipGraph replay of the whole step" if world == 1 else "hipGraph(fwd+bwd) -> RCCL all-reduce -> hipGraph(AdamW)")
+                                    if graphed is not None else "eager"},
                "loss": round(float(loss.item()), 4), "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(out), flush=True)
     if world > 1:

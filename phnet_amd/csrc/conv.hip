@@ -441,19 +441,20 @@ struct TileChoice { int bm, bn; };
 
 TileChoice pick_tile(long M, long N)
 {
-    // fill >= ~2 waves of workgroups over 256 CUs when the problem allows it, biggest tile first
-    const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
-    for (auto& c : cand) {
-        if (N <= 64 && c[1] == 128) continue;
-        if (ceil_div64(M, c[0]) * ceil_div64(N, c[1]) >= 512) return {c[0], c[1]};
-    }
-    if (N <= 64 || M > 4 * N) return {64, 64};
+    // Measured on MI355X (tests/tools/bench_conv.py): the problems of this path are small (a 5-frame clip), so what
+    // matters is the number of co-resident workgroups per CU, not the tile's arithmetic intensity: 64x64 tiles with
+    // the block count topped up to ~1250 by split-K beat the larger tiles on every trunk layer (72-80 us vs 85-130 us).
+    (void)M; (void)N;
     return {64, 64};
 }
 
 struct ConvPlan { int bm, bn, splits; long tiles; };
 
+// K-tile depth: 64 for the skinny (latency-bound) GEMMs of the lane head, 16 otherwise
+int k_tile_for(long M, int K) { return (M <= 2048 && K >= 64) ? 64 : BK; }
+
 int g_force_bm = 0, g_force_bn = 0, g_force_splits = 0;      // tuning aid (phnet_tune_force_conv_tile)
+int g_force_kt = 0;                                          // tuning aid (phnet_tune_force_k_tile)
 
 ConvPlan plan_conv(long M, int Co, int K, bool has_ws, size_t ws_bytes)
 {
@@ -467,9 +468,9 @@ ConvPlan plan_conv(long M, int Co, int K, bool has_ws, size_t ws_bytes)
         return f;
     }
     ConvPlan p{t.bm, t.bn, 1, ceil_div64(M, t.bm) * ceil_div64(Co, t.bn)};
-    // split K when the tile grid cannot fill the chip and K is long enough to amortise the reduce
-    if (has_ws && p.tiles < 256) {
-        int splits = (int)min((long)16, max((long)1, 512 / p.tiles));
+    // split K until ~1250 workgroups are in flight (about 5 per CU), keeping >= 256 of K per split
+    if (has_ws && p.tiles < 900) {
+        int splits = (int)min((long)8, max((long)1, (1250 + p.tiles / 2) / p.tiles));
         while (splits > 1 && K / splits < 256) --splits;
         while (splits > 1 && (size_t)splits * M * Co * sizeof(float) > ws_bytes) --splits;
         p.splits = splits;
@@ -490,8 +491,7 @@ int launch_conv(const float* X, const float* W, const float* bias, const float* 
     float* dst = splits > 1 ? workspace : out;
     dim3 grid((unsigned)tiles, 1, (unsigned)splits);
     // deep K tiles for skinny (latency-bound) problems: few row tiles and K long enough to fill them
-    const bool deep = M <= 2048 && K >= 64;
-    const int bkt = deep ? 64 : BK;
+    const int bkt = g_force_kt ? g_force_kt : k_tile_for(M, K);
     const int ksteps = (K + bkt - 1) / bkt;
     g.k_per_split = ((ksteps + splits - 1) / splits) * bkt;
 #define PHNET_LAUNCH_CONV_(BM_, BN_, BKT_)                                                                              \
@@ -509,7 +509,8 @@ int launch_conv(const float* X, const float* W, const float* bias, const float* 
     } while (0)
 #define PHNET_LAUNCH_CONV(BM_, BN_)                                                                                     \
     do {                                                                                                                \
-        if (deep) PHNET_LAUNCH_CONV_(BM_, BN_, 64);                                                                     \
+        if (bkt == 64) PHNET_LAUNCH_CONV_(BM_, BN_, 64);                                                                \
+        else if (bkt == 32) PHNET_LAUNCH_CONV_(BM_, BN_, 32);                                                           \
         else PHNET_LAUNCH_CONV_(BM_, BN_, 16);                                                                          \
     } while (0)
     if (t.bm == 128 && t.bn == 128) PHNET_LAUNCH_CONV(128, 128);
@@ -536,7 +537,7 @@ PHNET_API int phnet_conv2d_plan(int64_t M, int32_t Co, int32_t K, uint64_t ws_by
     if (M < 1 || Co < 1 || K < 1 || !bm || !bn || !splits || !k_tile) return PHNET_ERR_ARG;
     const ConvPlan p = plan_conv((long)M, Co, K, ws_bytes > 0, (size_t)ws_bytes);
     *bm = p.bm; *bn = p.bn; *splits = p.splits;
-    *k_tile = (M <= 2048 && K >= 64) ? 64 : BK;
+    *k_tile = g_force_kt ? g_force_kt : k_tile_for((long)M, K);
     return PHNET_OK;
 }
 
@@ -546,6 +547,13 @@ PHNET_API int phnet_tune_force_conv_tile(int32_t bm, int32_t bn, int32_t splits)
 {
     if (bm != 0 && !((bm == 64 || bm == 128) && (bn == 64 || bn == 128))) return PHNET_ERR_ARG;
     g_force_bm = bm; g_force_bn = bn; g_force_splits = splits;
+    return PHNET_OK;
+}
+
+PHNET_API int phnet_tune_force_k_tile(int32_t kt)
+{
+    if (kt != 0 && kt != 16 && kt != 32 && kt != 64) return PHNET_ERR_ARG;
+    g_force_kt = kt;
     return PHNET_OK;
 }
 

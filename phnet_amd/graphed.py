@@ -2,7 +2,8 @@
 
 The per-clip step is ~20 000 small launches (15 serial stage iterations); replaying them from a hipGraph removes the
 host from the loop.  Works because the training path is shape-static and sync-free (device-side label assignment,
-fixed-capacity memory tokens).  Single-process only (the DDP path stays eager)."""
+fixed-capacity memory tokens).  With data parallelism the gradient all-reduce runs eagerly between two graphs
+(forward+backward | optimizer)."""
 from typing import Callable, Optional
 
 import torch
@@ -10,8 +11,10 @@ import torch
 
 class GraphedTrainStep:
     def __init__(self, model: torch.nn.Module, optimizer: torch.optim.Optimizer, frames: torch.Tensor, lanes: torch.Tensor,
-                 loss_divisor: Optional[float] = None, warmup: int = 3, arena=None):
-        self.model, self.optimizer, self.arena = model, optimizer, arena
+                 loss_divisor: Optional[float] = None, warmup: int = 3, arena=None, between: Optional[Callable[[], None]] = None):
+        """between: optional callable run eagerly between backward and the optimizer step (the data-parallel gradient
+        all-reduce); the step is then recorded as two graphs (forward+backward | optimizer) around it."""
+        self.model, self.optimizer, self.arena, self.between = model, optimizer, arena, between
         self.frames, self.lanes = frames.clone(), lanes.clone()
         self.div = float(loss_divisor if loss_divisor is not None else frames.shape[0])
         side = torch.cuda.Stream()
@@ -22,13 +25,21 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
+        self.graph_opt = None
         if arena is None:
             optimizer.zero_grad(set_to_none=True)
-        with torch.cuda.graph(self.graph):
-            self.loss = self._step(zero=arena is not None)
+        if between is None:
+            with torch.cuda.graph(self.graph):
+                self.loss = self._step(zero=arena is not None)
+        else:
+            with torch.cuda.graph(self.graph):
+                self.loss = self._fwd_bwd(zero=arena is not None)
+            self.graph_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_opt, pool=self.graph.pool()):
+                self.optimizer.step()
         torch.cuda.synchronize()
 
-    def _step(self, zero: bool = True):
+    def _fwd_bwd(self, zero: bool = True):
         if zero:
             if self.arena is not None:
                 self.arena.zero()                       # one memset; .grad views stay alive
@@ -36,12 +47,21 @@ class GraphedTrainStep:
                 self.optimizer.zero_grad(set_to_none=True)
         loss = self.model({"frame": self.frames, "lanes": self.lanes}) / self.div
         loss.backward()
-        self.optimizer.step()
         return loss.detach()
+
+    def _step(self, zero: bool = True):
+        loss = self._fwd_bwd(zero)
+        if self.between is not None:
+            self.between()
+        self.optimizer.step()
+        return loss
 
     def __call__(self, frames: torch.Tensor, lanes: Optional[torch.Tensor] = None) -> torch.Tensor:
         self.frames.copy_(frames, non_blocking=True)
         if lanes is not None:
             self.lanes.copy_(lanes, non_blocking=True)
         self.graph.replay()
+        if self.graph_opt is not None:
+            self.between()
+            self.graph_opt.replay()
         return self.loss

@@ -129,7 +129,7 @@ def conv2d_fwd(x, w, bias, stride: int, pad: int, relu: bool = False, out: Optio
     ho, wo = conv_out_hw(hi, wi, r, s, stride, pad)
     if out is None:
         out = torch.empty((n, ho, wo, co), dtype=torch.float32, device=x.device)
-    ws = workspace(16 * n * ho * wo * co * 4 if n * ho * wo * co < (1 << 22) else 0, x.device)
+    ws = workspace(8 * n * ho * wo * co * 4 if n * ho * wo * co < (1 << 23) else 0, x.device)
     m, k = n * ho * wo, r * s * ci
     with _Timed(lambda: _gemm_symbol(m, co, k, ws.numel(), False), 2.0 * m * co * k):
         check(lib().phnet_conv2d_fwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(out), n, hi, wi, ci, co, r, s, stride, pad,
@@ -143,7 +143,7 @@ def conv2d_dgrad(dy, w, in_hw: Tuple[int, int], stride: int, pad: int, addend: O
     co, r, s, ci = w.shape
     hi, wi = in_hw
     dx = torch.empty((n, hi, wi, ci), dtype=torch.float32, device=dy.device)
-    ws = workspace(16 * n * hi * wi * ci * 4 if n * hi * wi * ci < (1 << 22) else 0, dy.device)
+    ws = workspace(8 * n * hi * wi * ci * 4 if n * hi * wi * ci < (1 << 23) else 0, dy.device)
     m, k = n * hi * wi, r * s * co
     with _Timed(lambda: _gemm_symbol(m, ci, k, ws.numel(), True), 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * co * r * s * ci):
         check(lib().phnet_conv2d_dgrad(_ptr(dy), _ptr(w), _ptr(addend), _ptr(dx), n, hi, wi, ci, co, r, s, stride, pad,

@@ -42,7 +42,7 @@ def test_argument_validation_needs_no_gpu(built):
     assert lib.phnet_roi_pool_fwd(None, None, None, None, None, 1, 240, 36, 10, 25, 32, None) == -1   # C != 64
     bm, bn, sp, kt = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
     assert lib.phnet_conv2d_plan(80000, 64, 576, 0, ctypes.byref(bm), ctypes.byref(bn), ctypes.byref(sp), ctypes.byref(kt)) == 0
-    assert (bm.value, bn.value, sp.value, kt.value) == (128, 64, 1, 16)
+    assert (bm.value, bn.value, sp.value, kt.value) == (64, 64, 1, 16)
     assert lib.phnet_conv2d_plan(240, 64, 128, 0, ctypes.byref(bm), ctypes.byref(bn), ctypes.byref(sp), ctypes.byref(kt)) == 0
     assert kt.value == 64
 

@@ -5,6 +5,7 @@ import torch
 from phnet_amd import hip_ops as K
 from phnet_amd._lib import lib
 
+TRUNK_ONLY = "--trunk" in sys.argv
 SHAPES = [  # name, N,Hi,Wi,Ci,Co,R,stride,pad
     ("layer1 3x3", 5, 80, 200, 64, 64, 3, 1, 1),
     ("layer2 3x3", 5, 40, 100, 128, 128, 3, 1, 1),
@@ -39,14 +40,21 @@ def timeit(fn, iters=20):
     return e0.elapsed_time(e1) / (5 * iters) * 1e3  # us
 
 def main():
-    for name, N, Hi, Wi, Ci, Co, R, st, pad in SHAPES:
+    for name, N, Hi, Wi, Ci, Co, R, st, pad in (SHAPES[:4] if TRUNK_ONLY else SHAPES):
         x = torch.randn(N, Hi, Wi, Ci, device="cuda"); w = torch.randn(Co, R, R, Ci, device="cuda") * 0.05
         ho, wo = K.conv_out_hw(Hi, Wi, R, R, st, pad)
         gy = torch.randn(N, ho, wo, Co, device="cuda")
         fl = 2.0 * N * ho * wo * Co * R * R * Ci
         res = []
-        for bm, bn in ([(0, 0)] if "--quick" in sys.argv else [(0, 0), (64, 64), (128, 64), (64, 128), (128, 128)]):
-            for sp in ([0] if bm == 0 else [1, 2, 4, 8, 16]):
+        ktiles = [0]
+        if "--ktile" in sys.argv:
+            ktiles = [16, 32, 64]
+        cfgs = [(0, 0)] if "--quick" in sys.argv else [(0, 0), (64, 64), (128, 64), (64, 128), (128, 128)]
+        if "--ktile" in sys.argv:
+            cfgs = [(64, 64), (128, 64)]
+        for kt_, (bm, bn) in [(k_, c_) for k_ in ktiles for c_ in cfgs]:
+            lib().phnet_tune_force_k_tile(kt_)
+            for sp in ([0] if bm == 0 else ([1, 2, 4] if "--ktile" in sys.argv else [1, 2, 4, 8, 16])):
                 M = N * ho * wo
                 if bm and sp > 1 and (M // bm + 1) * (Co // bn + 1) * sp > 4096: continue
                 lib().phnet_tune_force_conv_tile(bm, bn, sp)
@@ -55,12 +63,13 @@ def main():
                     td = timeit(lambda: K.conv2d_dgrad(gy, w, (Hi, Wi), st, pad)) if Ci >= 64 else float("nan")
                 except RuntimeError as e:
                     continue
-                res.append((bm, bn, sp, tf, td))
+                res.append((f'{bm:3d}x{bn:3d} kt{kt_:2d}', bn, sp, tf, td))
         lib().phnet_tune_force_conv_tile(0, 0, 0)
         tw = timeit(lambda: K.conv2d_wgrad(gy, x, w.shape, st, pad))
         print(f"== {name}: {fl/1e9:.2f} GF; wgrad {tw:.1f} us = {fl/tw/1e6:.1f} TF/s")
+        lib().phnet_tune_force_k_tile(0)
         for bm, bn, sp, tf, td in res:
-            print(f"   tile {bm:3d}x{bn:3d} splits {sp:2d}: fwd {tf:7.1f} us {fl/tf/1e6:6.1f} TF/s | dgrad {td:7.1f} us {fl/td/1e6:6.1f} TF/s")
+            print(f"   tile {bm} splits {sp:2d}: fwd {tf:7.1f} us {fl/tf/1e6:6.1f} TF/s | dgrad {td:7.1f} us {fl/td/1e6:6.1f} TF/s")
 
 if __name__ == "__main__":
     main()
