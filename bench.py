@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--height", type=int, default=320)
     ap.add_argument("--width", type=int, default=800)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-clips", type=int, default=2)
+    ap.add_argument("--cpu-clips", type=int, default=6)
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--eager", action="store_true", help="do not capture the step in a hipGraph (always eager for N>1)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL over xGMI; gloo only for "
@@ -155,32 +155,59 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)          # the job's time is its slowest rank's
+    dt = float(tmax.item())
     records, hip_ops.TIMER = hip_ops.TIMER, None
-    timer_note = "HIP events around every launch of the kernel inside the timed region"
+    timer_note = "HIP events around every launch of the kernel inside the timed region (eager)"
+    isolated = None
     if graphed is not None and not args.no_kernel_timer:
-        # individual launches inside a graph replay cannot be bracketed by events: time the same kernels on the same
-        # shapes with one instrumented eager step right after the timed region
+        # Launches inside a graph replay cannot be bracketed by events (hipEventRecord nodes carry no timestamps on
+        # ROCm 7.2).  Instead: run ONE instrumented eager step right after the timed region to collect every GEMM launch
+        # of a step (same kernels, same shapes, same buffers), then re-issue those launches grouped by kernel symbol
+        # inside small hipGraphs and time each graph with a pair of events: device-side duration per launch without
+        # host gaps.
         hip_ops.TIMER = []
         eager_step(0)
         torch.cuda.synchronize()
         records, hip_ops.TIMER = hip_ops.TIMER, None
-        timer_note = "HIP events around every launch of the kernel in one instrumented eager step run right after the timed (graph-replay) region"
+        groups = {}
+        for rec in records:
+            groups.setdefault(rec[0], []).append(rec)
+        isolated = {}
+        side = torch.cuda.Stream()
+        for sym, recs in groups.items():
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side):
+                    for rec in recs:
+                        rec[5]()
+                g.replay(); torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(3):
+                    g.replay()
+                e1.record(); torch.cuda.synchronize()
+                isolated[sym] = e0.elapsed_time(e1) / 3.0 * 1e-3            # seconds for all launches of the symbol
+            except Exception as e:                                      # noqa: BLE001
+                print(f"[bench] isolated timing of {sym} failed: {e}", file=sys.stderr)
+        timer_note = ("device time of the step's launches of this kernel symbol, re-issued back to back in a hipGraph "
+                      "(same shapes and buffers as the step) and bracketed by HIP events; split-K launches include their reduce kernel")
     steps_timed = args.steps if graphed is None else 1
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
     print(f"[bench] rank {rank}: {args.steps} timed steps in {dt:.3f} s", file=sys.stderr, flush=True)
 
     if rank == 0:
         roof = None
         if records:
+            # GEMM launches are grouped by kernel symbol (what rocprofv3 --stats also groups by)
             agg = {}
-            for sym, splits, flops, e0, e1 in records:
-                if splits != 1:
-                    continue                                   # bracket would include the split-K reduce kernel
+            for sym, splits, flops, e0, e1, _launch in records:
                 a = agg.setdefault(sym, [0, 0.0, 0.0])
                 a[0] += 1; a[1] += flops; a[2] += e0.elapsed_time(e1) * 1e-3
+            if isolated:
+                for sym, sec_ in isolated.items():
+                    agg[sym][2] = sec_
             total_gemm_s = sum(a[2] for a in agg.values())
             sym, (n, fl, sec) = max(agg.items(), key=lambda kv: kv[1][2])
             ach = fl / sec / 1e12

@@ -24,22 +24,19 @@ def _gemm_symbol(m, co, k, ws_bytes, dgrad):
     return f"conv_igemm_kernel<{bm.value}, {bn.value}, {'true' if dgrad else 'false'}, {kt.value}>", sp.value
 
 
-class _Timed:
-    def __init__(self, sym_fn, flops):
-        self.on = TIMER is not None
-        if self.on:
-            self.sym, self.splits = sym_fn()
-            self.flops = flops
-            self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-
-    def __enter__(self):
-        if self.on:
-            self.e0.record()
-
-    def __exit__(self, *a):
-        if self.on:
-            self.e1.record()
-            TIMER.append((self.sym, self.splits, self.flops, self.e0, self.e1))
+def _timed_launch(sym_fn, flops, launch):
+    """Runs `launch()`.  With the timer on, also records (symbol, split-K factor, FLOPs, start event, end event, launch):
+    bench.py re-launches the recorded closures in isolation inside small hipGraphs to get device-side durations that
+    are free of host launch gaps (the event pair around a live eager launch includes them for microsecond kernels)."""
+    if TIMER is None:
+        return launch()
+    sym, splits = sym_fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    out = launch()
+    e1.record()
+    TIMER.append((sym, splits, flops, e0, e1, launch))
+    return out
 
 
 def _stream() -> int:
@@ -131,9 +128,9 @@ def conv2d_fwd(x, w, bias, stride: int, pad: int, relu: bool = False, out: Optio
         out = torch.empty((n, ho, wo, co), dtype=torch.float32, device=x.device)
     ws = workspace(8 * n * ho * wo * co * 4 if n * ho * wo * co < (1 << 23) else 0, x.device)
     m, k = n * ho * wo, r * s * ci
-    with _Timed(lambda: _gemm_symbol(m, co, k, ws.numel(), False), 2.0 * m * co * k):
-        check(lib().phnet_conv2d_fwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(out), n, hi, wi, ci, co, r, s, stride, pad,
-                                     int(relu), _ptr(ws), ws.numel(), _stream()), "phnet_conv2d_fwd")
+    _timed_launch(lambda: _gemm_symbol(m, co, k, ws.numel(), False), 2.0 * m * co * k,
+                  lambda: check(lib().phnet_conv2d_fwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(out), n, hi, wi, ci, co, r, s, stride,
+                                                       pad, int(relu), _ptr(ws), ws.numel(), _stream()), "phnet_conv2d_fwd"))
     return out
 
 
@@ -145,9 +142,9 @@ def conv2d_dgrad(dy, w, in_hw: Tuple[int, int], stride: int, pad: int, addend: O
     dx = torch.empty((n, hi, wi, ci), dtype=torch.float32, device=dy.device)
     ws = workspace(8 * n * hi * wi * ci * 4 if n * hi * wi * ci < (1 << 23) else 0, dy.device)
     m, k = n * hi * wi, r * s * co
-    with _Timed(lambda: _gemm_symbol(m, ci, k, ws.numel(), True), 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * co * r * s * ci):
-        check(lib().phnet_conv2d_dgrad(_ptr(dy), _ptr(w), _ptr(addend), _ptr(dx), n, hi, wi, ci, co, r, s, stride, pad,
-                                       _ptr(ws), ws.numel(), _stream()), "phnet_conv2d_dgrad")
+    _timed_launch(lambda: _gemm_symbol(m, ci, k, ws.numel(), True), 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * co * r * s * ci,
+                  lambda: check(lib().phnet_conv2d_dgrad(_ptr(dy), _ptr(w), _ptr(addend), _ptr(dx), n, hi, wi, ci, co, r, s, stride,
+                                                         pad, _ptr(ws), ws.numel(), _stream()), "phnet_conv2d_dgrad"))
     return dx
 
 
@@ -163,8 +160,10 @@ def conv2d_wgrad(dy, x, w_shape, stride: int, pad: int, dw: Optional[torch.Tenso
         assert not accumulate
     need = lib().phnet_conv2d_wgrad_workspace(n, hi, wi, ci, co, r, s, stride, pad)
     ws = workspace(need, x.device)
-    check(lib().phnet_conv2d_wgrad(_ptr(dy), _ptr(x), _ptr(dw), _ptr(dbias), n, hi, wi, ci, co, r, s, stride, pad,
-                                   int(accumulate), _ptr(ws), ws.numel(), _stream()), "phnet_conv2d_wgrad")
+    ho, wo = conv_out_hw(hi, wi, r, s, stride, pad)
+    _timed_launch(lambda: (f"conv_wgrad_kernel<{128 if co >= 128 else 64}, 64>", 0), 2.0 * n * ho * wo * co * r * s * ci,
+                  lambda: check(lib().phnet_conv2d_wgrad(_ptr(dy), _ptr(x), _ptr(dw), _ptr(dbias), n, hi, wi, ci, co, r, s, stride,
+                                                         pad, int(accumulate), _ptr(ws), ws.numel(), _stream()), "phnet_conv2d_wgrad"))
     return dw
 
 
