@@ -170,6 +170,19 @@ int phnet_gate_stack_bwd(const float* gout, const float* x, const float* out, co
                          const float* saved, float* const* grads, int32_t N, int32_t C, int32_t P, float eps,
                          int32_t accumulate, void* workspace, uint64_t ws_bytes, void* stream);
 
+/* ---- fused attention core (heads of width 16, Lq/Lk <= 256): replaces the scale/bmm/mask/softmax/dropout/bmm chain inside
+ * nn.MultiheadAttention (libs/models/utils/transformer.py:275-298) and its backward.  q/k/v/o and the gradients are
+ * addressed with row strides (floats), heads packed along the row.  key_valid u8[Lk] optional; keep u8[H][Lq][Lk]
+ * optional dropout keep-mask (kept weights scaled by keep_scale); lse [H][Lq]. ---- */
+int phnet_attention_fwd(const float* q, const float* k, const float* v, const uint8_t* key_valid, const uint8_t* keep,
+                        float* o, float* lse, int32_t Lq, int32_t Lk, int32_t H, int32_t E,
+                        int64_t sq, int64_t sk, int64_t sv, int64_t so, float keep_scale, void* stream);
+int phnet_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* dout,
+                        const float* lse, const uint8_t* key_valid, const uint8_t* keep,
+                        float* dq, float* dk, float* dv, int32_t Lq, int32_t Lk, int32_t H, int32_t E,
+                        int64_t sq, int64_t sk, int64_t sv, int64_t so, int64_t sdq, int64_t sdk, int64_t sdv,
+                        float keep_scale, void* stream);
+
 /* ---- bias gradients: column sums of [M][C] ---- */
 uint64_t phnet_colsum_workspace(int64_t M, int32_t C);
 int phnet_colsum(const float* a, float* out, int64_t M, int32_t C, int32_t accumulate, void* workspace, uint64_t ws_bytes, void* stream);

@@ -1,0 +1,209 @@
+// Fused multi-head attention core for the cross-frame transformer of branch B (gfx950): softmax(Q K^T / sqrt(d)) V with
+// optional key-validity mask and an externally drawn dropout keep-mask, forward and backward, heads of width 16.
+//
+// Replaces the core of nn.MultiheadAttention as used by libs/models/utils/transformer.py:275-298 (self-attention over
+// the 240 anchor queries, cross-attention to <= 40 memory tokens; 8 heads x 16): per attention, ATen issues
+// ~12 launches forward (scale, bmm, mask, softmax, dropout, bmm, transposes) and ~20 backward; here 1 + 2.
+// The problems are tiny (240 x 240 x 16 per head) and latency-bound: no MFMA, fp32 FMAs, K/V of one head staged in
+// LDS, 4 lanes per query row (online softmax per lane, merged with shuffles).
+//
+// Tensors are addressed with row strides, so q/k/v may be column slices of a packed [L,3E] projection output and the
+// gradients are written straight into the packed gradient buffer.
+#include "common.h"
+
+namespace {
+
+constexpr int D = 16;                 // head width
+constexpr int NT = 256;
+constexpr int ROWS = NT / 4;          // 64 rows (queries or keys) per workgroup, 4 lanes each
+constexpr int MAXK = 256;             // keys per head held in LDS
+
+struct AttnShape { int Lq, Lk, H; long sq, sk, sv, so; float scale, keep_scale; };
+
+// 4 adjacent lanes -> one row: reduce across them
+__device__ __forceinline__ float quad_sum(float v) { v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); return v; }
+__device__ __forceinline__ float quad_max(float v) { v = fmaxf(v, __shfl_xor(v, 1, 64)); return fmaxf(v, __shfl_xor(v, 2, 64)); }
+
+__global__ __launch_bounds__(NT) void attn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                      const unsigned char* __restrict__ key_valid, const unsigned char* __restrict__ keep,
+                                                      float* __restrict__ o, float* __restrict__ lse, AttnShape g)
+{
+    __shared__ float Ks[MAXK][D + 1], Vs[MAXK][D + 1];
+    __shared__ unsigned char valid[MAXK];
+    const int h = blockIdx.x, row = blockIdx.y * ROWS + (threadIdx.x >> 2), part = threadIdx.x & 3;
+    for (int i = threadIdx.x; i < g.Lk * D; i += NT) {
+        const int kk = i / D, d = i - kk * D;
+        Ks[kk][d] = k[(size_t)kk * g.sk + h * D + d];
+        Vs[kk][d] = v[(size_t)kk * g.sv + h * D + d];
+    }
+    for (int i = threadIdx.x; i < g.Lk; i += NT) valid[i] = key_valid ? key_valid[i] : 1;
+    __syncthreads();
+    const bool live = row < g.Lq;
+    float qr[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) qr[d] = live ? q[(size_t)row * g.sq + h * D + d] * g.scale : 0.f;
+    float m = -INFINITY, l = 0.f, acc[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) acc[d] = 0.f;
+    const unsigned char* kp = keep ? keep + ((size_t)h * g.Lq + (live ? row : 0)) * g.Lk : nullptr;
+    for (int kk = part; kk < g.Lk; kk += 4) {
+        if (!valid[kk]) continue;
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) s += qr[d] * Ks[kk][d];
+        const float mn = fmaxf(m, s);
+        const float c = expf(m - mn), e = expf(s - mn);
+        l = l * c + e;
+        const float ed = (kp && !kp[kk]) ? 0.f : e * g.keep_scale;
+#pragma unroll
+        for (int d = 0; d < D; ++d) acc[d] = acc[d] * c + ed * Vs[kk][d];
+        m = mn;
+    }
+    // merge the 4 partial (m, l, acc) of the row
+    const float mt = quad_max(m);
+    const float c = (m == -INFINITY) ? 0.f : expf(m - mt);
+    l = quad_sum(l * c);
+#pragma unroll
+    for (int d = 0; d < D; ++d) acc[d] = quad_sum(acc[d] * c);
+    if (live && part == 0) {
+        const float inv = l > 0.f ? 1.0f / l : 0.f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) o[(size_t)row * g.so + h * D + d] = acc[d] * inv;
+        lse[(size_t)h * g.Lq + row] = mt + logf(l);
+    }
+}
+
+// role 0 (blockIdx.z == 0): dQ for a tile of 64 queries;  role 1: dK, dV for a tile of 64 keys.
+__global__ __launch_bounds__(NT) void attn_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                      const float* __restrict__ o, const float* __restrict__ dout,
+                                                      const float* __restrict__ lse, const unsigned char* __restrict__ key_valid,
+                                                      const unsigned char* __restrict__ keep,
+                                                      float* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv,
+                                                      AttnShape g, long sdq, long sdk, long sdv, int q_tiles)
+{
+    __shared__ float As[MAXK][D + 1], Bs[MAXK][D + 1];     // role 0: K, V of the head; role 1: Q*scale, dO of the head
+    __shared__ float Dl[MAXK], Ls[MAXK];                   // role 1: rowsum(dO*O), lse per query
+    __shared__ unsigned char valid[MAXK];
+    const int h = blockIdx.x;
+    const bool dq_role = (int)blockIdx.y < q_tiles;
+    const int tile = dq_role ? blockIdx.y : blockIdx.y - q_tiles;
+    const int row = tile * ROWS + (threadIdx.x >> 2), part = threadIdx.x & 3;
+    for (int i = threadIdx.x; i < g.Lk; i += NT) valid[i] = key_valid ? key_valid[i] : 1;
+    if (dq_role) {
+        for (int i = threadIdx.x; i < g.Lk * D; i += NT) {
+            const int kk = i / D, d = i - kk * D;
+            As[kk][d] = k[(size_t)kk * g.sk + h * D + d];
+            Bs[kk][d] = v[(size_t)kk * g.sv + h * D + d];
+        }
+        __syncthreads();
+        const bool live = row < g.Lq;
+        const int r = live ? row : 0;
+        float qr[D], dor[D], delta = 0.f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            qr[d] = q[(size_t)r * g.sq + h * D + d] * g.scale;
+            dor[d] = dout[(size_t)r * g.so + h * D + d];
+            delta += dor[d] * o[(size_t)r * g.so + h * D + d];
+        }
+        const float L = lse[(size_t)h * g.Lq + r];
+        const unsigned char* kp = keep ? keep + ((size_t)h * g.Lq + r) * g.Lk : nullptr;
+        float acc[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) acc[d] = 0.f;
+        for (int kk = part; kk < g.Lk; kk += 4) {
+            if (!valid[kk]) continue;
+            float s = 0.f, dp = 0.f;
+#pragma unroll
+            for (int d = 0; d < D; ++d) { s += qr[d] * As[kk][d]; dp += dor[d] * Bs[kk][d]; }
+            const float p = expf(s - L);
+            if (kp && !kp[kk]) dp = 0.f; else dp *= g.keep_scale;
+            const float ds = p * (dp - delta);
+#pragma unroll
+            for (int d = 0; d < D; ++d) acc[d] += ds * As[kk][d];
+        }
+#pragma unroll
+        for (int d = 0; d < D; ++d) acc[d] = quad_sum(acc[d]);
+        if (live && part == 0)
+#pragma unroll
+            for (int d = 0; d < D; ++d) dq[(size_t)row * sdq + h * D + d] = acc[d] * g.scale;
+    } else {
+        // stage Q*scale, dO, delta, lse of ALL queries of this head (Lq <= MAXK)
+        for (int i = threadIdx.x; i < g.Lq * D; i += NT) {
+            const int qq = i / D, d = i - qq * D;
+            As[qq][d] = q[(size_t)qq * g.sq + h * D + d] * g.scale;
+            Bs[qq][d] = dout[(size_t)qq * g.so + h * D + d];
+        }
+        __syncthreads();
+        for (int qq = threadIdx.x; qq < g.Lq; qq += NT) {
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < D; ++d) s += Bs[qq][d] * o[(size_t)qq * g.so + h * D + d];
+            Dl[qq] = s;
+            Ls[qq] = lse[(size_t)h * g.Lq + qq];
+        }
+        __syncthreads();
+        const bool live = row < g.Lk;
+        const int r = live ? row : 0;
+        float kr[D], vr[D], dkr[D], dvr[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            kr[d] = k[(size_t)r * g.sk + h * D + d];
+            vr[d] = v[(size_t)r * g.sv + h * D + d];
+            dkr[d] = 0.f; dvr[d] = 0.f;
+        }
+        const bool kvalid = live && valid[r];
+        if (kvalid)
+            for (int qq = part; qq < g.Lq; qq += 4) {
+                float s = 0.f, dp = 0.f;
+#pragma unroll
+                for (int d = 0; d < D; ++d) { s += As[qq][d] * kr[d]; dp += Bs[qq][d] * vr[d]; }
+                const float p = expf(s - Ls[qq]);
+                const bool kept = !keep || keep[((size_t)h * g.Lq + qq) * g.Lk + r];
+                const float pd = kept ? p * g.keep_scale : 0.f;       // dropped attention weight
+                const float ds = p * ((kept ? dp * g.keep_scale : 0.f) - Dl[qq]);
+#pragma unroll
+                for (int d = 0; d < D; ++d) { dvr[d] += pd * Bs[qq][d]; dkr[d] += ds * As[qq][d]; }
+            }
+#pragma unroll
+        for (int d = 0; d < D; ++d) { dkr[d] = quad_sum(dkr[d]); dvr[d] = quad_sum(dvr[d]); }
+        if (live && part == 0)
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                dk[(size_t)row * sdk + h * D + d] = dkr[d];           // As already carries the 1/sqrt(d) scale
+                dv[(size_t)row * sdv + h * D + d] = dvr[d];
+            }
+    }
+}
+
+bool attn_ok(int Lq, int Lk, int H, int E) { return Lq >= 1 && Lk >= 1 && Lq <= MAXK && Lk <= MAXK && H >= 1 && E == H * D; }
+
+}  // namespace
+
+// q [Lq][.] row stride sq, k/v [Lk][.] row strides sk/sv (heads packed along the row: column h*16+d); o [Lq][.] stride so;
+// key_valid (optional) u8[Lk]; keep (optional, training dropout) u8[H][Lq][Lk], kept weights are scaled by keep_scale
+// = 1/(1-p); lse [H][Lq] saved for the backward.  Lq, Lk <= 256, head width 16.
+PHNET_API int phnet_attention_fwd(const float* q, const float* k, const float* v, const uint8_t* key_valid, const uint8_t* keep,
+                                  float* o, float* lse, int32_t Lq, int32_t Lk, int32_t H, int32_t E,
+                                  int64_t sq, int64_t sk, int64_t sv, int64_t so, float keep_scale, void* stream)
+{
+    if (!attn_ok(Lq, Lk, H, E) || !q || !k || !v || !o || !lse) return PHNET_ERR_ARG;
+    AttnShape g{Lq, Lk, H, sq, sk, sv, so, 1.0f / sqrtf((float)D), keep ? keep_scale : 1.0f};
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(H, (Lq + ROWS - 1) / ROWS), dim3(NT), 0, (hipStream_t)stream,
+                       q, k, v, key_valid, keep, o, lse, g);
+    return phnet_launch_status();
+}
+
+// dq [Lq][.] stride sdq, dk/dv [Lk][.] strides sdk/sdv are overwritten (rows of masked keys get zeros).
+PHNET_API int phnet_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* dout,
+                                  const float* lse, const uint8_t* key_valid, const uint8_t* keep,
+                                  float* dq, float* dk, float* dv, int32_t Lq, int32_t Lk, int32_t H, int32_t E,
+                                  int64_t sq, int64_t sk, int64_t sv, int64_t so, int64_t sdq, int64_t sdk, int64_t sdv,
+                                  float keep_scale, void* stream)
+{
+    if (!attn_ok(Lq, Lk, H, E) || !q || !k || !v || !o || !dout || !lse || !dq || !dk || !dv) return PHNET_ERR_ARG;
+    AttnShape g{Lq, Lk, H, sq, sk, sv, so, 1.0f / sqrtf((float)D), keep ? keep_scale : 1.0f};
+    const int qt = (Lq + ROWS - 1) / ROWS, kt = (Lk + ROWS - 1) / ROWS;
+    hipLaunchKernelGGL(attn_bwd_kernel, dim3(H, qt + kt), dim3(NT), 0, (hipStream_t)stream,
+                       q, k, v, o, dout, lse, key_valid, keep, dq, dk, dv, g, (long)sdq, (long)sdk, (long)sdv, qt);
+    return phnet_launch_status();
+}

@@ -204,25 +204,60 @@ def lane_update(priors, head, ys, img_w, img_h):
 
 
 # ---------------------------------------------------------------------------------------------------------
-# Ops still on ATen device kernels in this round (listed in DESIGN.md "Not yet hand-written"): the per-anchor
-# batched 36x64x128 products of the dynamic head and the 240 x <=40 attention core of branch B.
+# Still on ATen device kernels in this round (DESIGN.md "Not yet hand-written"): the per-anchor batched 36x64x128
+# products of the dynamic head.
 # ---------------------------------------------------------------------------------------------------------
 def bmm(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return torch.bmm(a, b)
 
 
-def attention_core(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, dropout_p: float = 0.0,
-                   key_valid: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """q [L,E], k/v [M,E] -> softmax(q k^T / sqrt(d)) v, heads split along E; key_valid bool[M] masks padded keys."""
-    L, e = q.shape
-    d = e // heads
-    qh = q.reshape(L, heads, d).transpose(0, 1) * (1.0 / (d ** 0.5))
-    kh = k.reshape(-1, heads, d).transpose(0, 1)
-    vh = v.reshape(-1, heads, d).transpose(0, 1)
-    logits = torch.bmm(qh, kh.transpose(1, 2))
-    if key_valid is not None:
-        logits = logits.masked_fill(~key_valid[None, None, :], float("-inf"))
-    att = torch.softmax(logits, dim=-1)
-    if dropout_p > 0.0:
-        att = torch.nn.functional.dropout(att, dropout_p)
-    return torch.bmm(att, vh).transpose(0, 1).reshape(L, e)
+class _Attention(torch.autograd.Function):
+    """softmax(q k^T / sqrt(d)) v per head on the fused HIP kernels.  `packed` is either the [L,3E] output of the
+    self-attention projection (q|k|v column blocks) or None; otherwise q [Lq,E] and kv [M,2E] (k|v) are separate.
+    Gradients are written straight into packed buffers of the same layout."""
+
+    @staticmethod
+    def forward(ctx, heads, dropout_p, key_valid, q_in, kv_in):
+        e = q_in.shape[1] // 3 if kv_in is None else q_in.shape[1]
+        q_in = q_in.contiguous()
+        if kv_in is None:                      # self-attention, packed projection
+            q, k, v = q_in[:, :e], q_in[:, e:2 * e], q_in[:, 2 * e:]
+        else:
+            kv_in = kv_in.contiguous()
+            q, k, v = q_in, kv_in[:, :e], kv_in[:, e:]
+        keep, scale = None, 1.0
+        if dropout_p > 0.0:
+            keep = (torch.rand((heads, q.shape[0], k.shape[0]), device=q.device) >= dropout_p).to(torch.uint8)
+            scale = 1.0 / (1.0 - dropout_p)
+        kvu8 = None if key_valid is None else key_valid.to(torch.uint8).contiguous()
+        out, lse = K.attention_fwd(q, k, v, heads, kvu8, keep, scale)
+        ctx.save_for_backward(q_in, kv_in, out, lse, kvu8, keep)
+        ctx.heads, ctx.scale, ctx.e = heads, scale, e
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q_in, kv_in, out, lse, kvu8, keep = ctx.saved_tensors
+        e = ctx.e
+        dq_in = torch.empty_like(q_in)
+        if kv_in is None:
+            q, k, v = q_in[:, :e], q_in[:, e:2 * e], q_in[:, 2 * e:]
+            dq, dk, dv = dq_in[:, :e], dq_in[:, e:2 * e], dq_in[:, 2 * e:]
+            dkv_in = None
+        else:
+            dkv_in = torch.empty_like(kv_in)
+            q, k, v = q_in, kv_in[:, :e], kv_in[:, e:]
+            dq, dk, dv = dq_in, dkv_in[:, :e], dkv_in[:, e:]
+        K.attention_bwd(q, k, v, out, dout.contiguous(), lse, ctx.heads, dq, dk, dv, kvu8, keep, ctx.scale)
+        return None, None, None, dq_in, dkv_in
+
+
+def attention_packed(qkv: torch.Tensor, heads: int, dropout_p: float = 0.0) -> torch.Tensor:
+    """Self-attention on a packed [L,3E] projection."""
+    return _Attention.apply(heads, dropout_p, None, qkv, None)
+
+
+def attention_cross(q: torch.Tensor, kv: torch.Tensor, heads: int, dropout_p: float = 0.0,
+                    key_valid: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Cross-attention: q [Lq,E], kv [M,2E] packed (k|v), optional bool key mask [M]."""
+    return _Attention.apply(heads, dropout_p, key_valid, q, kv)

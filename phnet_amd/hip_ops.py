@@ -483,3 +483,26 @@ def gate_stack_bwd(gout, x, out, params, saved, grads, eps: float, accumulate: b
     ws = workspace(lib().phnet_gate_stack_bwd_workspace(n, c, p), x.device, 3)
     check(lib().phnet_gate_stack_bwd(_ptr(gout), _ptr(x), _ptr(out), _ptr_array(params), _ptr(saved), _ptr_array(grads),
                                      n, c, p, eps, int(accumulate), _ptr(ws), ws.numel(), _stream()), "phnet_gate_stack_bwd")
+
+
+def attention_fwd(q, k, v, heads: int, key_valid=None, keep=None, keep_scale: float = 1.0):
+    """q [Lq,E], k/v [Lk,E] (any row stride, unit column stride) -> (o [Lq,E], lse [H,Lq])."""
+    lq, e = q.shape
+    lk = k.shape[0]
+    assert q.stride(1) == 1 and k.stride(1) == 1 and v.stride(1) == 1
+    out = torch.empty((lq, e), dtype=torch.float32, device=q.device)
+    lse = torch.empty((heads, lq), dtype=torch.float32, device=q.device)
+    check(lib().phnet_attention_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(key_valid), _ptr(keep), _ptr(out), _ptr(lse), lq, lk, heads, e,
+                                    q.stride(0), k.stride(0), v.stride(0), out.stride(0), float(keep_scale), _stream()),
+          "phnet_attention_fwd")
+    return out, lse
+
+
+def attention_bwd(q, k, v, o, dout, lse, heads: int, dq, dk, dv, key_valid=None, keep=None, keep_scale: float = 1.0):
+    """Writes dq/dk/dv (views with arbitrary row stride)."""
+    lq, e = q.shape
+    lk = k.shape[0]
+    check(lib().phnet_attention_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(dout), _ptr(lse), _ptr(key_valid), _ptr(keep),
+                                    _ptr(dq), _ptr(dk), _ptr(dv), lq, lk, heads, e, q.stride(0), k.stride(0), v.stride(0),
+                                    o.stride(0), dq.stride(0), dk.stride(0), dv.stride(0), float(keep_scale), _stream()),
+          "phnet_attention_bwd")

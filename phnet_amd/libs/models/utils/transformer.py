@@ -14,14 +14,14 @@ def _attention(mha: nn.MultiheadAttention, q_in: torch.Tensor, kv_in: torch.Tens
     """q_in [L,E], kv_in [M,E] (batch 1) -> [L,E]; key_valid bool[M] masks padded memory slots."""
     e, h = mha.embed_dim, mha.num_heads
     w, b = mha.in_proj_weight, mha.in_proj_bias
+    p_drop = mha.dropout if training else 0.0
     if q_in is kv_in:
         qkv = PF.linear(q_in, w, b)                       # self-attention: one [L,3E] projection on the whole in_proj
-        q, k, v = qkv[:, :e], qkv[:, e:2 * e], qkv[:, 2 * e:]
+        out = PF.attention_packed(qkv, h, p_drop)
     else:
         q = PF.linear(q_in, w[:e], b[:e])
         kv = PF.linear(kv_in, w[e:], b[e:])
-        k, v = kv[:, :e], kv[:, e:]
-    out = PF.attention_core(q, k, v, h, mha.dropout if training else 0.0, key_valid)
+        out = PF.attention_cross(q, kv, h, p_drop, key_valid)
     return PF.linear(out, mha.out_proj.weight, mha.out_proj.bias)
 
 

@@ -330,3 +330,44 @@ def test_dwconv3x3_fwd_bwd(ops):
     close(ops.dwconv3x3(dev(g.float()[0]), wd, None, flip=True), x.grad[0], 1e-5)
     dw, db = ops.dwconv3x3_wgrad(dev(g.float()[0]), xd)
     close(dw, w.grad, 2e-5); close(db, b.grad, 2e-5)
+
+
+@pytest.mark.parametrize("Lq,Lk,masked,drop", [(240, 240, False, False), (240, 40, True, False), (240, 5, True, False),
+                                                (240, 40, True, True), (240, 240, False, True), (7, 3, False, False)])
+def test_fused_attention_fwd_bwd(ops, Lq, Lk, masked, drop):
+    torch.manual_seed(Lq + Lk)
+    H, E = 8, 128
+    q = torch.randn(Lq, E, dtype=torch.float64, requires_grad=True)
+    k = torch.randn(Lk, E, dtype=torch.float64, requires_grad=True)
+    v = torch.randn(Lk, E, dtype=torch.float64, requires_grad=True)
+    valid = torch.ones(Lk, dtype=torch.bool)
+    if masked:
+        valid[torch.randperm(Lk)[: max(1, Lk // 3)]] = False
+        valid[-1] = True
+    keep = (torch.rand(H, Lq, Lk) >= 0.1) if drop else None
+    scale = 1.0 / 0.9 if drop else 1.0
+    qh = q.view(Lq, H, 16).transpose(0, 1) * 0.25
+    kh, vh = k.view(Lk, H, 16).transpose(0, 1), v.view(Lk, H, 16).transpose(0, 1)
+    logits = (qh @ kh.transpose(1, 2)).masked_fill(~valid[None, None, :], float("-inf"))
+    att = torch.softmax(logits, dim=-1)
+    if drop:
+        att = att * keep.double() * scale
+    ref = (att @ vh).transpose(0, 1).reshape(Lq, E)
+    g = torch.randn_like(ref)
+    ref.backward(g)
+    qd, kd, vd = dev(q.detach().float()), dev(k.detach().float()), dev(v.detach().float())
+    vu8 = valid.to(torch.uint8).cuda() if masked else None
+    ku8 = keep.to(torch.uint8).cuda().contiguous() if drop else None
+    out, lse = ops.attention_fwd(qd, kd, vd, H, vu8, ku8, scale)
+    close(out, ref, 2e-5)
+    dq, dk, dv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
+    ops.attention_bwd(qd, kd, vd, out, dev(g.float()), lse, H, dq, dk, dv, vu8, ku8, scale)
+    close(dq, q.grad, 5e-5); close(dk, k.grad, 5e-5); close(dv, v.grad, 5e-5)
+    # packed self-attention layout: q|k|v column blocks of one [L,3E] buffer, gradients into a packed buffer
+    if Lq == Lk and not masked:
+        pk = torch.cat([qd, kd, vd], dim=1).contiguous()
+        o2, lse2 = ops.attention_fwd(pk[:, :E], pk[:, E:2 * E], pk[:, 2 * E:], H, None, ku8, scale)
+        close(o2, ref, 2e-5)
+        dpk = torch.zeros_like(pk)
+        ops.attention_bwd(pk[:, :E], pk[:, E:2 * E], pk[:, 2 * E:], o2, dev(g.float()), lse2, H, dpk[:, :E], dpk[:, E:2 * E], dpk[:, 2 * E:], None, ku8, scale)
+        close(dpk[:, :E], q.grad, 5e-5); close(dpk[:, E:2 * E], k.grad, 5e-5); close(dpk[:, 2 * E:], v.grad, 5e-5)
