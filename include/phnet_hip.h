@@ -40,6 +40,16 @@ int phnet_lane_nms(const float* rows, const float* scores, const int32_t* counts
                    int64_t k_max, int32_t n_offsets, float thresh, int64_t top_k,
                    int64_t* keep, int64_t* num_to_keep, int64_t* parent, void* stream);
 
+/* ---- fused eval decode: replaces DetNetV2.get_lanes up to the kept rows (libs/models/Router4OL.py:441-471: softmax +
+ * confidence mask + boolean-mask compaction + NMS rows + libs.ops.nms + keep[:num] + gather + length rounding) in one
+ * launch without host synchronisation.  lines [frames][N][6+S], N <= 256, top_k <= 64.  keep_mask u8 [frames][N];
+ * num i64 [frames]; keep_c i64 [frames][top_k] (indices into the compacted candidate list, NMS order, -1 padded = the
+ * reference's `keep`); anchors / anchors_sorted i64 [frames][top_k] (anchor indices, NMS order / ascending);
+ * kept_rows [frames][top_k][6+S] (column 5 rounded to strips; zero rows beyond num). */
+int phnet_lane_decode(const float* lines, int64_t frames, int32_t N, int32_t n_offsets, float conf_thresh,
+                      float nms_thresh, int64_t top_k, float img_w, uint8_t* keep_mask, int64_t* num,
+                      int64_t* keep_c, int64_t* anchors, int64_t* anchors_sorted, float* kept_rows, void* stream);
+
 /* ---- lane-anchor ROI pooling: replaces F.grid_sample(..., align_corners=True) + permutes
  * (libs/models/Router4OL.py:132-150, 269-272) and its backward (ATen grid_sampler_2d_backward).
  * fmap [B][h][w][64]; xs [B][N][P] = priors_on_featmap (un-flipped); ys [P] = prior_feat_ys; out [B][N][P][64]. */

@@ -65,3 +65,28 @@ class GraphedTrainStep:
             self.between()
             self.graph_opt.replay()
         return self.loss
+
+
+class GraphedInference:
+    """Eval forward of a fixed-length clip (backbone + lane head + fused decode/NMS for every frame) captured in one
+    hipGraph; `__call__` copies the frames in, replays, and returns the device-resident (kept_rows, num, anchors)."""
+
+    def __init__(self, model: torch.nn.Module, frames: torch.Tensor, warmup: int = 2):
+        self.model = model.eval()
+        self.frames = frames.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(warmup):
+                model.infer_device(self.frames)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph):
+            self.out = model.infer_device(self.frames)
+        torch.cuda.synchronize()
+
+    def __call__(self, frames: torch.Tensor):
+        self.frames.copy_(frames, non_blocking=True)
+        self.graph.replay()
+        return self.out

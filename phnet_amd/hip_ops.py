@@ -506,3 +506,21 @@ def attention_bwd(q, k, v, o, dout, lse, heads: int, dq, dk, dv, key_valid=None,
                                     _ptr(dq), _ptr(dk), _ptr(dv), lq, lk, heads, e, q.stride(0), k.stride(0), v.stride(0),
                                     o.stride(0), dq.stride(0), dk.stride(0), dv.stride(0), float(keep_scale), _stream()),
           "phnet_attention_bwd")
+
+
+def lane_decode(lines, conf_thresh: float, nms_thresh: float, top_k: int, img_w: int):
+    """lines [N,6+S] or [F,N,6+S] -> dict(keep_mask u8, num i64, keep_c, anchors, anchors_sorted i64 [..,top_k],
+    kept_rows [..,top_k,6+S]); everything stays on the device (no sync)."""
+    _req(lines, name="lines")
+    batched = lines.dim() == 3
+    f = lines.shape[0] if batched else 1
+    n, w = lines.shape[-2], lines.shape[-1]
+    dev = lines.device
+    out = dict(keep_mask=torch.empty((f, n), dtype=torch.uint8, device=dev), num=torch.empty((f,), dtype=torch.int64, device=dev),
+               keep_c=torch.empty((f, top_k), dtype=torch.int64, device=dev), anchors=torch.empty((f, top_k), dtype=torch.int64, device=dev),
+               anchors_sorted=torch.empty((f, top_k), dtype=torch.int64, device=dev),
+               kept_rows=torch.empty((f, top_k, w), dtype=torch.float32, device=dev))
+    check(lib().phnet_lane_decode(_ptr(lines), f, n, w - 6, float(conf_thresh), float(nms_thresh), int(top_k), float(img_w),
+                                  _ptr(out["keep_mask"]), _ptr(out["num"]), _ptr(out["keep_c"]), _ptr(out["anchors"]),
+                                  _ptr(out["anchors_sorted"]), _ptr(out["kept_rows"]), _stream()), "phnet_lane_decode")
+    return out if batched else {k: v[0] for k, v in out.items()}

@@ -248,6 +248,13 @@ class DetNetV2(nn.Module):
                               metadata={"start_x": row[3], "start_y": row[2], "conf": row[1]}))
         return lanes
 
+    def decode_device(self, lines: torch.Tensor):
+        """lines [N,6+S] (blended predictions of one frame) -> device-resident decode (hip_ops.lane_decode): the
+        sync-free form of get_lanes - confidence mask, NMS and the gathered kept rows in one launch."""
+        from phnet_amd import hip_ops as K
+        tp = self.cfg.test_parameters
+        return K.lane_decode(lines.contiguous(), tp.conf_threshold, tp.nms_thres, self.cfg.max_lanes, self.img_w)
+
     def get_lanes(self, output, org_size=None, crop_size=0, as_lanes=True):
         """output [B,N,6+S] blended lines -> (decoded per batch item, keep_inds, keep) as in Router4OL.py:437-479."""
         decoded, keep_inds, keep = [], None, []
@@ -284,15 +291,46 @@ class RouterOL(nn.Module):
         self.save_freq_max = cfg.save_freq_max
         self.crop_size = cfg.dscfg.crop_size
         self.org_size = (cfg.dscfg.org_height, cfg.dscfg.org_width)
+        self.sync_free_eval = True      # eval: fused device-side decode, one D2H copy per clip (False: per-frame get_lanes)
+
+    def _begin_clip(self):
+        self.detNet._branch_cache = None                                       # weights may have changed since the last clip
+        for head in self.detNet.DHead_series:
+            head.begin_clip()
+
+    def infer_device(self, frame: torch.Tensor):
+        """Eval forward of one clip without any host synchronisation (hipGraph-capturable): returns
+        (kept_rows [T,max_lanes,6+S], num [T], anchors [T,max_lanes]) on the device."""
+        self._begin_clip()
+        feats = self.backbone(frame)
+        last_cuts, rows, nums, anchors = [], [], [], []
+        for t in range(frame.shape[0]):
+            cur = tuple(f[t:t + 1] for f in feats)
+            outputs, cur_cut, gates = self.detNet(cur, last_cuts)
+            d = torch.stack(gates, dim=0).mean(dim=0)
+            lines = outputs["predictions_sec"][-1] * d + outputs["predictions_fir"][-1] * (1 - d)
+            dec = self.detNet.decode_device(lines[0])
+            rows.append(dec["kept_rows"]); nums.append(dec["num"]); anchors.append(dec["anchors"])
+            last_cuts.append([self._tokens(feat.detach(), dec["anchors_sorted"]) for feat in cur_cut])
+            if t >= self.save_freq_max:
+                last_cuts.pop(0)
+        self._begin_clip()
+        return torch.stack(rows), torch.stack(nums), torch.stack(anchors)
+
+    def lanes_from_device(self, kept_rows: torch.Tensor, nums: torch.Tensor):
+        """One device->host copy per clip, then the host-side Lane construction (Router4OL.py:394-435)."""
+        rows, n = kept_rows.cpu(), nums.cpu().tolist()
+        return {"lane_lines": [self.detNet.predictions_to_pred(rows[t, :n[t]]) if n[t] else [] for t in range(len(n))]}
 
     def forward(self, inputs: dict):
         frame, lanes = inputs.values()
         if not frame.is_cuda:
             raise RuntimeError("phnet_amd runs on the GPU only: move the model and the clip to cuda")
+        if not self.training and self.sync_free_eval:
+            rows, nums, _ = self.infer_device(frame)
+            return self.lanes_from_device(rows, nums)
         T = frame.shape[0]
-        self.detNet._branch_cache = None                                       # weights may have changed since the last clip
-        for head in self.detNet.DHead_series:
-            head.begin_clip()
+        self._begin_clip()
         feats = self.backbone(frame)                                           # 3 x [T,h,w,C] NHWC
         last_cuts = []
         total_loss = 0.0
@@ -315,9 +353,7 @@ class RouterOL(nn.Module):
                     last_cuts.append(self.saveMemory4Test(keep_inds, keep, cur_cut))
                 if t >= self.save_freq_max:
                     last_cuts.pop(0)
-        self.detNet._branch_cache = None
-        for head in self.detNet.DHead_series:
-            head.begin_clip()
+        self._begin_clip()
         return total_loss if self.training else clip_outputs
 
     def _tokens(self, feat, rows):

@@ -371,3 +371,30 @@ def test_fused_attention_fwd_bwd(ops, Lq, Lk, masked, drop):
         dpk = torch.zeros_like(pk)
         ops.attention_bwd(pk[:, :E], pk[:, E:2 * E], pk[:, 2 * E:], o2, dev(g.float()), lse2, H, dpk[:, :E], dpk[:, E:2 * E], dpk[:, 2 * E:], None, ku8, scale)
         close(dpk[:, :E], q.grad, 5e-5); close(dpk[:, E:2 * E], k.grad, 5e-5); close(dpk[:, 2 * E:], v.grad, 5e-5)
+
+
+@pytest.mark.parametrize("seed,thr", [(0, 0.5), (1, 0.5), (2, 0.9), (3, 0.999999), (4, 0.0)])
+def test_lane_decode_matches_oracle_decode(ops, seed, thr):
+    """Fused decode vs the oracle's decode_frame (softmax threshold + NMS rows + oracle NMS + gather)."""
+    from oracle import lane_nms as ON
+    from oracle import phnet_cpu as O
+    g = O.Geometry(conf_threshold=thr)
+    r = np.random.default_rng(seed)
+    pri, _ = O.priors_from_embeddings(O.initial_anchor_embeddings(g), g)
+    lines = pri.clone()
+    lines[:, :2] = torch.from_numpy(r.normal(0, 2, (240, 2)).astype(np.float32))
+    lines[:, 2:5] += torch.from_numpy(r.normal(0, 0.02, (240, 3)).astype(np.float32))
+    lines[:, 5] = torch.from_numpy(r.uniform(0.2, 0.9, 240).astype(np.float32))
+    lines[:, 6:] += torch.from_numpy(r.normal(0, 0.01, (240, 36)).astype(np.float32))
+    ref = O.decode_frame(lines.clone(), g, ON.lane_nms)
+    out = ops.lane_decode(dev(lines), thr, g.nms_thres, g.max_lanes, g.img_w)
+    assert (out["keep_mask"].cpu().numpy().astype(bool) == ref["keep_inds"].numpy()).all()
+    n = int(out["num"])
+    assert n == len(ref["keep"])
+    assert out["keep_c"][:n].cpu().tolist() == ref["keep"].tolist()
+    want_anchor = torch.where(ref["keep_inds"])[0][ref["keep"]].tolist()
+    assert out["anchors"][:n].cpu().tolist() == want_anchor
+    assert out["anchors_sorted"][:n].cpu().tolist() == sorted(want_anchor)
+    assert out["anchors"][n:].cpu().tolist() == [-1] * (4 - n)
+    if n:
+        assert torch.equal(out["kept_rows"][:n].cpu(), ref["kept_rows"])

@@ -150,6 +150,7 @@ def _eval_case(g, T, gold_file):
     gold = _gold(gold_file)
     model = _build(g)
     model.eval()
+    model.sync_free_eval = False          # this test hooks get_lanes (the reference-shaped per-frame path)
     rec = {"lines": [], "keep_inds": [], "keep": []}
     det = model.detNet
     gl = det.get_lanes
@@ -344,3 +345,34 @@ def test_fused_frame_loss_equals_tensor_op_criterion():
         for i, (t, gr) in enumerate(zip(preds + gates, ref_g)):
             scale = float(gr.abs().max()) + 1e-8
             assert float((t.grad - gr).abs().max()) <= 2e-4 * scale + 1e-7, (n_lanes, i, float((t.grad - gr).abs().max()), scale)
+
+
+@pytest.mark.parametrize("cfg", ["tiny", "config2"])
+def test_sync_free_eval_and_graph_replay_match_reference_goldens(cfg):
+    """Fused device-side decode (phnet_lane_decode) + hipGraph-captured inference against the reference's eval goldens:
+    keep masks / kept anchors exact, lane polylines within tolerance."""
+    from phnet_amd.graphed import GraphedInference
+    if cfg == "tiny":
+        g, T, gold = O.Geometry(img_h=64, img_w=160, arch="resnet18"), 4, _gold("tiny_r18_64x160.npz")
+    else:
+        g, T, gold = O.Geometry(arch="resnet34"), 5, _gold("config2_r34_320x800.npz")
+    model = _build(g).eval()
+    frames = synth.make_clip(g, T, seed=77).cuda()
+    with torch.no_grad():
+        res = model({"frame": frames, "lanes": None})                       # sync-free path (default)
+        rows, nums, anchors = model.infer_device(frames)
+    graphed = GraphedInference(model, torch.zeros_like(frames))
+    rows_g, nums_g, anchors_g = graphed(frames)
+    torch.cuda.synchronize()
+    assert torch.equal(nums_g, nums) and torch.equal(anchors_g, anchors)
+    _close(rows_g, rows, 1e-5, "graph replay rows")
+    for t in range(T):
+        want_anchor = np.where(gold["eval_keep_inds"][t])[0][[i for i in gold["eval_keep"][t].tolist() if i >= 0]]
+        n = int(nums[t])
+        assert anchors[t, :n].cpu().tolist() == want_anchor.tolist(), t        # kept lanes (NMS order) as anchor ids: exact
+        lanes = res["lane_lines"][t]
+        assert len(lanes) == int((gold["eval_lane_npts"][t] > 0).sum())
+        for j, lane in enumerate(lanes):
+            k = int(gold["eval_lane_npts"][t, j])
+            assert lane.points.shape == (k, 2)
+            np.testing.assert_allclose(lane.points, gold["eval_lane_pts"][t, j, :k], atol=ACT_TOL)
