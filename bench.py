@@ -104,7 +104,10 @@ def main():
     from phnet_amd.arena import GradArena
     if world > 1:                                   # same initial weights on every rank (DDP's constructor broadcast)
         for t_ in list(model.parameters()) + list(model.buffers()):
-            dist.broadcast(t_.data, src=0)
+            d_ = t_.data
+            if d_.dim() == 4 and not d_.is_contiguous():
+                d_ = d_.permute(0, 2, 3, 1)          # channels_last parameter: broadcast its dense OHWI view
+            dist.broadcast(d_, src=0)
     arena = GradArena(model.parameters())          # flat fp32 gradient buffer; HIP backward kernels accumulate into it
     decay = [p for p in model.parameters() if p.dim() > 1]
     no_decay = [p for p in model.parameters() if p.dim() <= 1]

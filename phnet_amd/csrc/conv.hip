@@ -500,7 +500,7 @@ int launch_conv(const float* X, const float* W, const float* bias, const float* 
                                      (DGRAD ? KStridedTile<BN_, BKT_>::FLOATS : KContigTile<BN_, BKT_>::FLOATS)) * 4;   \
         static bool attr_set_ = false;                                                                                  \
         if (lds_ > 64 * 1024 && !attr_set_) {                                                                           \
-            hipFuncSetAttribute((const void*)conv_igemm_kernel<BM_, BN_, DGRAD, BKT_>,                                  \
+            (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BM_, BN_, DGRAD, BKT_>,                            \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_);                                 \
             attr_set_ = true;                                                                                           \
         }                                                                                                               \
@@ -608,6 +608,9 @@ static long wgrad_splits(long P, long Co, long NC, int* bm_out)
     const long tiles = ceil_div64(Co, bm) * ceil_div64(NC, 64);
     long splits = max((long)1, min((long)256, 768 / max((long)1, tiles)));
     splits = max((long)1, min(splits, P / 64));
+    // the M=240 linears of the lane head: 15 K steps in all - a split would only add a reduce launch (6 us) to a
+    // 10 us kernel; unsplit launches also accumulate straight into the gradient arena
+    if (P <= 1024) splits = 1;
     if (bm_out) *bm_out = bm;
     return splits;
 }

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(ROI_THREADS) void roi_pool_bwd_kernel(
         const size_t plane = (size_t)b * h * w * ROI_C + lane;
         const bool x0in = c.x0 >= 0 && c.x0 < w, x1in = c.x0 + 1 >= 0 && c.x0 + 1 < w;
         const bool y0in = c.y0 >= 0 && c.y0 < h, y1in = c.y0 + 1 >= 0 && c.y0 + 1 < h;
-        const float fx = floorf(c.ix), fy = floorf(c.iy);
+        const float fy = floorf(c.iy);
         const float ye = fy + 1.0f;
         if (y0in && x0in) {
             const size_t o = plane + ((size_t)c.y0 * w + c.x0) * ROI_C;

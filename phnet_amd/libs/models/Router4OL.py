@@ -8,7 +8,6 @@ through phnet_amd.hip_ops (C-ABI -> gfx950 kernels).  There is no CPU path: tens
 import copy
 import math
 
-import numpy as np
 import torch
 import torch.nn as nn
 
@@ -129,19 +128,6 @@ class DetNetV2(nn.Module):
         return self._expand_anchors(self.prior_embeddings.weight)
 
     # ---- the two branches --------------------------------------------------------------------------------------
-    @staticmethod
-    def _tower(mods, x):
-        for m in mods:
-            if isinstance(m, nn.Linear):
-                x = PF.linear(x, m.weight, m.bias, relu=True)      # every Linear of a tower is followed by its ReLU
-        return x
-
-    def _update(self, priors, cls, reg, off):
-        syx_t = priors[..., 2:5] + torch.tanh(reg[..., :3])
-        xs = self._line_xs(syx_t[..., 0:1], syx_t[..., 1:2], syx_t[..., 2:3])
-        lines = torch.cat([cls, syx_t, reg[..., 3:4], xs], dim=-1)
-        return torch.cat([cls, syx_t, reg[..., 3:4], xs + off], dim=-1), lines
-
     def _branch_weights(self, sec: bool):
         """The three towers (cls / reg / offsets) of one branch as ONE 3-GEMM chain: layer 1 weights concatenated
         ([3C,C]: the towers share their input), layer 2 block-diagonal ([3C,3C]), output heads block-structured

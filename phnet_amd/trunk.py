@@ -121,13 +121,6 @@ class EncoderFunction(torch.autograd.Function):
             if bias is not None:
                 put(bias, dbt)
 
-        def bias_grad_into(p, dy):
-            d = direct_grad(p)
-            if d is not None:
-                K.colsum(dy.view(-1, dy.shape[-1]), out=d, accumulate=True)
-            else:
-                put(p, K.colsum(dy.view(-1, dy.shape[-1])))
-
         # ---- FPN ------------------------------------------------------------------------------------------
         douts = [d.contiguous() for d in (d3, d4, d5)]
         dl = []
