@@ -221,6 +221,14 @@ def main():
                     traffic = pmc[short]["hbm_bytes_per_launch_corrected"]
             except Exception:                              # noqa: BLE001
                 traffic = None
+            mfma_util = None
+            try:                                           # separate PMC pass on the backbone conv shapes (profiles/README.md)
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_mfma_trunk.json")))
+                vals = [v["mfma_util_pct"] for k, v in pm.items() if ", 16>" in k or "wgrad" in k]
+                mfma_util = {"min": min(vals), "max": max(vals), "source": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE on "
+                             "tests/tools/bench_conv.py --trunk (ResNet-34 stage convs of a 5x320x800 clip), profiles/r01_pmc_mfma_trunk.json"}
+            except Exception:                              # noqa: BLE001
+                mfma_util = None
             ach = fl / sec / 1e12
             roof = {"bound": "mfma", "kernel": sym, "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
@@ -231,7 +239,8 @@ def main():
                     "mfma_dtype": "f32 (v_mfma_f32_32x32x2_f32)",
                     "all_gemm_kernels": {k: {"launches": v[0], "TFLOP/s": round(v[1] / v[2] / 1e12, 2), "ms_per_step": round(v[2] / steps_timed * 1e3, 3)}
                                          for k, v in sorted(agg.items())},
-                    "gemm_ms_per_step": round(total_gemm_s / steps_timed * 1e3, 3), "timing": timer_note}
+                    "gemm_ms_per_step": round(total_gemm_s / steps_timed * 1e3, 3), "timing": timer_note,
+                    "backbone_conv_mfma_util_pct": mfma_util}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args)

@@ -455,6 +455,7 @@ int k_tile_for(long M, int K) { return (M <= 2048 && K >= 64) ? 64 : BK; }
 
 int g_force_bm = 0, g_force_bn = 0, g_force_splits = 0;      // tuning aid (phnet_tune_force_conv_tile)
 int g_force_kt = 0;                                          // tuning aid (phnet_tune_force_k_tile)
+int g_wgrad_bm128 = 1, g_wgrad_target = 768;                // tuning aids (phnet_tune_wgrad)
 
 ConvPlan plan_conv(long M, int Co, int K, bool has_ws, size_t ws_bytes)
 {
@@ -550,6 +551,13 @@ PHNET_API int phnet_tune_force_conv_tile(int32_t bm, int32_t bn, int32_t splits)
     return PHNET_OK;
 }
 
+PHNET_API int phnet_tune_wgrad(int32_t allow_bm128, int32_t target_blocks)
+{
+    if (target_blocks < 1) return PHNET_ERR_ARG;
+    g_wgrad_bm128 = allow_bm128; g_wgrad_target = target_blocks;
+    return PHNET_OK;
+}
+
 PHNET_API int phnet_tune_force_k_tile(int32_t kt)
 {
     if (kt != 0 && kt != 16 && kt != 32 && kt != 64) return PHNET_ERR_ARG;
@@ -604,13 +612,14 @@ PHNET_API int phnet_conv2d_dgrad(const float* dy, const float* w, const float* a
 // workspace must hold splits*Co*R*S*Ci floats; query with phnet_conv2d_wgrad_workspace.
 static long wgrad_splits(long P, long Co, long NC, int* bm_out)
 {
-    const int bm = Co >= 128 ? 128 : 64;
+    const int bm = (Co >= 128 && g_wgrad_bm128) ? 128 : 64;
     const long tiles = ceil_div64(Co, bm) * ceil_div64(NC, 64);
-    long splits = max((long)1, min((long)256, 768 / max((long)1, tiles)));
+    const long target = tiles >= 64 ? max((long)g_wgrad_target, (long)1250) : (long)g_wgrad_target;   // measured: bench_conv --wgrad
+    long splits = max((long)1, min((long)256, target / max((long)1, tiles)));
     splits = max((long)1, min(splits, P / 64));
-    // the M=240 linears of the lane head: 15 K steps in all - a split would only add a reduce launch (6 us) to a
-    // 10 us kernel; unsplit launches also accumulate straight into the gradient arena
-    if (P <= 1024) splits = 1;
+    // the M=240 linears of the lane head (15 K steps in all): with >= 32 tiles a split only adds a reduce launch;
+    // unsplit launches also accumulate straight into the gradient arena
+    if (P <= 1024 && tiles >= 32) splits = 1;
     if (bm_out) *bm_out = bm;
     return splits;
 }

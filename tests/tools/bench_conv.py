@@ -67,6 +67,13 @@ def main():
         lib().phnet_tune_force_conv_tile(0, 0, 0)
         tw = timeit(lambda: K.conv2d_wgrad(gy, x, w.shape, st, pad))
         print(f"== {name}: {fl/1e9:.2f} GF; wgrad {tw:.1f} us = {fl/tw/1e6:.1f} TF/s")
+        if "--wgrad" in sys.argv:
+            for bm128 in (1, 0):
+                for target in (512, 768, 1250, 2000, 3000):
+                    lib().phnet_tune_wgrad(bm128, target)
+                    tw = timeit(lambda: K.conv2d_wgrad(gy, x, w.shape, st, pad))
+                    print(f"   wgrad bm128={bm128} target={target:5d}: {tw:7.1f} us {fl/tw/1e6:6.1f} TF/s")
+            lib().phnet_tune_wgrad(1, 768)
         lib().phnet_tune_force_k_tile(0)
         for bm, bn, sp, tf, td in res:
             print(f"   tile {bm} splits {sp:2d}: fwd {tf:7.1f} us {fl/tf/1e6:6.1f} TF/s | dgrad {td:7.1f} us {fl/td/1e6:6.1f} TF/s")
