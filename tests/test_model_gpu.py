@@ -376,3 +376,27 @@ def test_sync_free_eval_and_graph_replay_match_reference_goldens(cfg):
             k = int(gold["eval_lane_npts"][t, j])
             assert lane.points.shape == (k, 2)
             np.testing.assert_allclose(lane.points, gold["eval_lane_pts"][t, j, :k], atol=ACT_TOL)
+
+
+def test_ten_frame_clip_exercises_memory_fifo_vs_oracle():
+    """T = 10 > save_freq_max = 8: the cross-frame memory FIFO pops its oldest frame (Router4OL.py:555-556).
+    Loss of the HIP model vs the CPU oracle on the same clip (config-4-like clip length on the tiny geometry)."""
+    g = O.Geometry(img_h=64, img_w=160, arch="resnet18")
+    T = 10
+    frames, lanes = synth.make_clip(g, T, seed=5), synth.make_targets(g, T)
+    model = _build(g).train()
+    rec, undo = _record_heads(model)
+    loss = model({"frame": frames.cuda(), "lanes": lanes.cuda()})
+    loss.backward()
+    torch.cuda.synchronize()
+    undo()
+    col = {}
+    ref = O.clip_forward(synth.make_state(g), frames, lanes, g, training=True, collect=col)
+    assert abs(loss.item() - ref.item()) <= 2e-3 * abs(ref.item()), (loss.item(), ref.item())
+    agree = 0
+    for t in range(T):
+        for s in range(3):
+            agree += rec["matched"][t][s].tolist() == col["positives"][t][s].tolist()
+    assert agree >= 27, agree                      # label assignment: identical on (almost) every frame x stage
+    assert rec["matched"][0][0].tolist() == col["positives"][0][0].tolist()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
