@@ -286,6 +286,7 @@ __global__ __launch_bounds__(256) void gate_ln_grad_reduce_kernel(const float* _
     if (col >= 18L * CP) return;
     const int j = (int)(col / CP), i = (int)(col - (long)j * CP);
     double s = 0.0;
+#pragma unroll 8
     for (int n = 0; n < N; ++n) s += (double)lnpart[((size_t)n * 18 + j) * CP + i];
     // parameter slot of LayerNorm j: 0,1 -> ln0 (w,b); then block b: ln1 (w,b) at 2+8b+2, ln2 (w,b) at 2+8b+6
     int slot;

@@ -189,7 +189,8 @@ __global__ void layernorm_bwd_param_finalize_kernel(const float* __restrict__ pa
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= L) return;
     double sw = 0.0, sb = 0.0;
-    for (int s = 0; s < slabs; ++s) {
+#pragma unroll 8
+    for (int s = 0; s < slabs; ++s) {                 // independent loads: unrolled so that they are in flight together
         sw += (double)partial[((size_t)s * 2 + 0) * L + c];
         sb += (double)partial[((size_t)s * 2 + 1) * L + c];
     }

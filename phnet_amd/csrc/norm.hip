@@ -310,6 +310,7 @@ __global__ void colsum_finalize_kernel(const float* __restrict__ part, float* __
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     double t = 0.0;
+#pragma unroll 8
     for (int s = 0; s < slabs; ++s) t += (double)part[(size_t)s * C + c];
     out[c] = accumulate ? out[c] + (float)t : (float)t;
 }
