@@ -194,6 +194,17 @@ int phnet_attention_bwd(const float* q, const float* k, const float* v, const fl
                         int64_t sq, int64_t sk, int64_t sv, int64_t so, int64_t sdq, int64_t sdk, int64_t sdv,
                         float keep_scale, void* stream);
 
+/* ---- per-anchor dynamic convolution: y[n] = relu(LayerNorm_J(x[n] @ w[n]) * gamma + beta), replacing torch.bmm + norm1/norm2
+ * + ReLU in libs/models/utils/dynamic_head.py:40-51 (and their backward).  x [N][P][K], w [N][K][J] (generated per anchor),
+ * y [N][P][J], stats [N][P][2] = (mean, rstd) (NULL = inference).  J <= 128; J and K divide 256.  Backward: dx optional,
+ * dw [N][K][J], dgamma/dbeta [J] overwritten or accumulated; workspace N*2*J floats. ---- */
+int phnet_dyn_bmm_ln_relu_fwd(const float* x, const float* w, const float* gamma, const float* beta, float* y,
+                              float* stats, int32_t N, int32_t P, int32_t K, int32_t J, float eps, void* stream);
+int phnet_dyn_bmm_ln_relu_bwd(const float* dy, const float* x, const float* w, const float* y, const float* stats,
+                              const float* gamma, float* dx, float* dw, float* dgamma, float* dbeta,
+                              int32_t N, int32_t P, int32_t K, int32_t J, float eps, int32_t param_accumulate,
+                              void* workspace, uint64_t ws_bytes, void* stream);
+
 /* ---- bias gradients: column sums of [M][C] ---- */
 uint64_t phnet_colsum_workspace(int64_t M, int32_t C);
 int phnet_colsum(const float* a, float* out, int64_t M, int32_t C, int32_t accumulate, void* workspace, uint64_t ws_bytes, void* stream);

@@ -94,6 +94,36 @@ def layer_norm(x, w, b, res=None, relu: bool = False, eps: float = 1e-5):
     return _LayerNorm.apply(x, w, b, res, relu, eps)
 
 
+class _DynBmmLnRelu(torch.autograd.Function):
+    """relu(LayerNorm(x[n] @ w[n])) per anchor as one launch each way (dynamic_head.py:40-51)."""
+
+    @staticmethod
+    def forward(ctx, x, w, gamma, beta, eps):
+        xc, wc = x.contiguous(), w.contiguous()
+        gc, bc = gamma.contiguous(), beta.contiguous()
+        need = any(ctx.needs_input_grad)
+        y, stats = K.dyn_bmm_ln_relu_fwd(xc, wc, gc, bc, eps, save_stats=need)
+        if need:
+            ctx.save_for_backward(xc, wc, y, stats, gc)
+        ctx.eps = eps
+        ctx.g_direct, ctx.b_direct = direct_grad(gamma), direct_grad(beta)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y, stats, gamma = ctx.saved_tensors
+        if ctx.g_direct is not None and ctx.b_direct is not None:
+            dx, dw, _, _ = K.dyn_bmm_ln_relu_bwd(dy.contiguous(), x, w, y, stats, gamma, ctx.eps, ctx.needs_input_grad[0],
+                                                 dgamma=ctx.g_direct.view(-1), dbeta=ctx.b_direct.view(-1), accumulate=True)
+            return dx, dw, None, None, None
+        dx, dw, dg, db = K.dyn_bmm_ln_relu_bwd(dy.contiguous(), x, w, y, stats, gamma, ctx.eps, ctx.needs_input_grad[0])
+        return dx, dw, dg, db, None
+
+
+def dyn_bmm_ln_relu(x, w, gamma, beta, eps: float = 1e-5):
+    return _DynBmmLnRelu.apply(x, w, gamma, beta, eps)
+
+
 class _DwConv(torch.autograd.Function):
     """Per-anchor depth-wise 3x3 over [N,C,P] planes (Conv2d(N,N,3,padding=1,groups=N) on [1,N,C,P])."""
 
@@ -201,14 +231,6 @@ class _LaneUpdate(torch.autograd.Function):
 
 def lane_update(priors, head, ys, img_w, img_h):
     return _LaneUpdate.apply(priors, head, ys, img_w, img_h)
-
-
-# ---------------------------------------------------------------------------------------------------------
-# Still on ATen device kernels in this round (DESIGN.md "Not yet hand-written"): the per-anchor batched 36x64x128
-# products of the dynamic head.
-# ---------------------------------------------------------------------------------------------------------
-def bmm(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
-    return torch.bmm(a, b)
 
 
 class _Attention(torch.autograd.Function):

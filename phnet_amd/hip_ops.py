@@ -376,6 +376,37 @@ def layernorm_bwd(dy, x, y, w, mean, rstd, relu: bool, need_dres: bool = False,
     return dx, dres, dw, db
 
 
+def dyn_bmm_ln_relu_fwd(x, w, gamma, beta, eps: float, save_stats: bool = True):
+    """x [N,P,K], w [N,K,J] -> (y [N,P,J], stats [N,P,2] or None)."""
+    _req(x, name="x"); _req(w, name="w")
+    n, p, k = x.shape
+    j = w.shape[2]
+    if w.shape[0] != n or w.shape[1] != k or gamma.numel() != j:
+        raise ValueError(f"dyn_bmm_ln_relu: x {tuple(x.shape)} / w {tuple(w.shape)} / gamma {tuple(gamma.shape)} mismatch")
+    y = torch.empty((n, p, j), dtype=torch.float32, device=x.device)
+    stats = torch.empty((n, p, 2), dtype=torch.float32, device=x.device) if save_stats else None
+    check(lib().phnet_dyn_bmm_ln_relu_fwd(_ptr(x), _ptr(w), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(stats), n, p, k, j, eps, _stream()),
+          "phnet_dyn_bmm_ln_relu_fwd")
+    return y, stats
+
+
+def dyn_bmm_ln_relu_bwd(dy, x, w, y, stats, gamma, eps: float, need_dx: bool = True,
+                        dgamma: Optional[torch.Tensor] = None, dbeta: Optional[torch.Tensor] = None, accumulate: bool = False):
+    """Returns (dx or None, dw, dgamma, dbeta)."""
+    _req(dy, name="dy")
+    n, p, k = x.shape
+    j = w.shape[2]
+    dx = torch.empty_like(x) if need_dx else None
+    dw = torch.empty_like(w)
+    if dgamma is None:
+        dgamma, dbeta, accumulate = torch.empty_like(gamma), torch.empty_like(gamma), False
+    ws = workspace(n * 2 * j * 4, x.device, 2)
+    check(lib().phnet_dyn_bmm_ln_relu_bwd(_ptr(dy), _ptr(x), _ptr(w), _ptr(y), _ptr(stats), _ptr(gamma), _ptr(dx), _ptr(dw),
+                                          _ptr(dgamma), _ptr(dbeta), n, p, k, j, eps, int(accumulate), _ptr(ws), ws.numel(), _stream()),
+          "phnet_dyn_bmm_ln_relu_bwd")
+    return dx, dw, dgamma, dbeta
+
+
 def dwconv3x3(x, w, bias, flip: bool = False):
     """x [N,C,P] planes, w [N,3,3] (or [N,1,3,3]), bias [N] or None."""
     _req(x, name="x"); _req(w, name="w")

@@ -48,11 +48,9 @@ class DynamicConv(nn.Module):
         l1, l2, lo = self.dynamic_layer_1, self.dynamic_layer_2, self.out_layer
         we, be = self._fold("dynamic_layer_1", l1)
         w1 = PF.linear(pro, we, be).view(b * n, c, 2 * c)
-        f = PF.bmm(roi, w1)
-        f = PF.layer_norm(f, self.norm1.weight, self.norm1.bias, relu=True, eps=self.norm1.eps)
+        f = PF.dyn_bmm_ln_relu(roi, w1, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         w2 = PF.linear(PF.linear(f.detach().reshape(b * n, -1), l2[0].weight, l2[0].bias), l2[1].weight, l2[1].bias)
-        f = PF.bmm(f, w2.view(b * n, 2 * c, c))
-        f = PF.layer_norm(f, self.norm2.weight, self.norm2.bias, relu=True, eps=self.norm2.eps)
+        f = PF.dyn_bmm_ln_relu(f, w2.view(b * n, 2 * c, c), self.norm2.weight, self.norm2.bias, self.norm2.eps)
         wo, bo = self._fold("out_layer", lo)
         f = PF.linear(f.reshape(b * n, -1), wo, bo)
         f = PF.layer_norm(f, self.norm3.weight, self.norm3.bias, eps=self.norm3.eps)

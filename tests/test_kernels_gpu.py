@@ -316,6 +316,32 @@ def test_layernorm_fwd_bwd(ops, rows, L, relu, res):
         close(dres, r.grad, 1e-6)
 
 
+@pytest.mark.parametrize("N,P,K,J", [(240, 36, 64, 128), (240, 36, 128, 64), (7, 36, 32, 64), (3, 5, 64, 32)])
+def test_dynamic_head_bmm_layernorm_relu(ops, N, P, K, J):
+    """relu(LayerNorm(x[n] @ w[n])) per anchor (dynamic_head.py:40-51) vs an fp64 torch reference."""
+    torch.manual_seed(N + K)
+    x = torch.randn(N, P, K, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn(N, K, J, dtype=torch.float64) / K ** 0.5).requires_grad_(True)
+    ga = (torch.rand(J, dtype=torch.float64) + 0.5).requires_grad_(True)
+    be = torch.randn(J, dtype=torch.float64, requires_grad=True)
+    y = F.relu(F.layer_norm(torch.bmm(x, w), [J], ga, be, 1e-5))
+    g = torch.randn_like(y)
+    y.backward(g)
+    xd, wd, gd, bd = (dev(t.detach().float()) for t in (x, w, ga, be))
+    yd, stats = ops.dyn_bmm_ln_relu_fwd(xd, wd, gd, bd, 1e-5)
+    close(yd, y, 2e-5)
+    y_inf, none = ops.dyn_bmm_ln_relu_fwd(xd, wd, gd, bd, 1e-5, save_stats=False)
+    assert none is None and torch.equal(y_inf, yd)
+    dx, dw, dg, db = ops.dyn_bmm_ln_relu_bwd(dev(g.float()), xd, wd, yd, stats, gd, 1e-5)
+    close(dx, x.grad, 5e-5); close(dw, w.grad, 5e-5); close(dg, ga.grad, 5e-5); close(db, be.grad, 5e-5)
+    # accumulate mode adds to the destinations; dx may be skipped
+    acc_g, acc_b = torch.ones_like(gd), torch.ones_like(gd)
+    dx2, dw2, _, _ = ops.dyn_bmm_ln_relu_bwd(dev(g.float()), xd, wd, yd, stats, gd, 1e-5, need_dx=False,
+                                             dgamma=acc_g, dbeta=acc_b, accumulate=True)
+    assert dx2 is None and torch.equal(dw2, dw)
+    close(acc_g - 1.0, ga.grad, 5e-5); close(acc_b - 1.0, be.grad, 5e-5)
+
+
 def test_dwconv3x3_fwd_bwd(ops):
     torch.manual_seed(9)
     N, C, P = 240, 64, 36
