@@ -40,8 +40,39 @@ class GradArena:
             _DIRECT.pop(id(p), None)
 
 
+class _GradSink(torch.autograd.Function):
+    """Identity over a weight that is DERIVED once per clip (folded Linear pairs, the concatenated / block-diagonal tower
+    weights) and then used by every frame and stage of the clip.  The HIP weight-gradient kernels of those uses accumulate
+    straight into `buf`; autograd sees no gradient from them and this node hands `buf` on once, instead of the engine
+    summing 15 per-use gradients with 14 add kernels per derived tensor."""
+
+    @staticmethod
+    def forward(ctx, w, buf):
+        ctx.set_materialize_grads(False)
+        ctx.buf = buf
+        return w.detach()
+
+    @staticmethod
+    def backward(ctx, g):
+        return (ctx.buf if g is None else ctx.buf + g), None
+
+
+def grad_sink(w: torch.Tensor) -> torch.Tensor:
+    """Returns `w` as a tensor whose gradient is gathered in a zero-initialised side buffer (see _GradSink)."""
+    if not (torch.is_grad_enabled() and w.requires_grad):
+        return w
+    w = w.contiguous()
+    buf = torch.zeros_like(w)
+    out = _GradSink.apply(w, buf)
+    out._phnet_sink = buf
+    return out
+
+
 def direct_grad(p) -> Optional[torch.Tensor]:
-    """The arena view to accumulate into, or None when `p` is not an arena-backed parameter."""
+    """The buffer to accumulate into (arena view of a parameter, or the side buffer of a grad_sink tensor), or None."""
+    sink = getattr(p, "_phnet_sink", None)
+    if sink is not None:
+        return sink
     if isinstance(p, torch.nn.Parameter) and id(p) in _DIRECT and p.grad is not None:
         return p.grad
     return None

@@ -15,8 +15,13 @@ class _Linear(torch.autograd.Function):
     Output widths that are not a multiple of 4 (the 1/2-wide score heads) are zero-padded to 4 for the kernel."""
 
     @staticmethod
-    def forward(ctx, x, w, b, relu):
+    def forward(ctx, x, w, b, relu, rows=None):
         x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        w_full, b_full = w, b
+        ctx.rows, ctx.full_n = rows, w.shape[0]
+        if rows is not None:                       # a row block of a packed projection (MultiheadAttention.in_proj_*)
+            w = w[rows[0]:rows[1]]
+            b = None if b is None else b[rows[0]:rows[1]]
         n = w.shape[0]
         npad = (-n) % 4
         wc = w.contiguous() if npad == 0 else torch.cat([w, w.new_zeros(npad, w.shape[1])], 0)
@@ -25,8 +30,11 @@ class _Linear(torch.autograd.Function):
         ctx.save_for_backward(x2, wc, y if relu else None)
         ctx.relu, ctx.has_b, ctx.xshape, ctx.n = relu, b is not None, x.shape, n
         # arena-backed parameters: the backward kernels accumulate straight into .grad (phnet_amd/arena.py)
-        ctx.w_direct = direct_grad(w) if npad == 0 else None
-        ctx.b_direct = direct_grad(b) if (npad == 0 and b is not None) else None
+        ctx.w_direct = direct_grad(w_full) if npad == 0 else None
+        ctx.b_direct = direct_grad(b_full) if (npad == 0 and b is not None) else None
+        if rows is not None:
+            ctx.w_direct = None if ctx.w_direct is None else ctx.w_direct[rows[0]:rows[1]]
+            ctx.b_direct = None if ctx.b_direct is None else ctx.b_direct[rows[0]:rows[1]]
         out = y if npad == 0 else y[:, :n]
         return out.reshape(*x.shape[:-1], n)
 
@@ -58,11 +66,18 @@ class _Linear(torch.autograd.Function):
                 K.colsum(g, out=ctx.b_direct, accumulate=True)
             else:
                 db = K.colsum(g)[:n]
-        return dx, dw, db, None
+        if ctx.rows is not None:                   # no arena: hand autograd full-size gradients of the packed parameter
+            r0, r1 = ctx.rows
+            if dw is not None:
+                full = dw.new_zeros(ctx.full_n, dw.shape[1]); full[r0:r1] = dw; dw = full
+            if db is not None:
+                full = db.new_zeros(ctx.full_n); full[r0:r1] = db; db = full
+        return dx, dw, db, None, None
 
 
-def linear(x, w, b=None, relu: bool = False):
-    return _Linear.apply(x, w, b, relu)
+def linear(x, w, b=None, relu: bool = False, rows=None):
+    """y = relu?(x @ w[rows].T + b[rows]); `rows=(r0, r1)` selects a row block of a packed weight without an autograd slice."""
+    return _Linear.apply(x, w, b, relu, rows)
 
 
 class _LayerNorm(torch.autograd.Function):

@@ -12,6 +12,7 @@ import torch
 import torch.nn as nn
 
 from phnet_amd import functional as PF
+from phnet_amd.arena import grad_sink
 from phnet_amd.trunk import encoder_forward
 from ..ops import nms
 from ..utils.lane import Lane
@@ -152,7 +153,7 @@ class DetNetV2(nn.Module):
             if pad:
                 wh = torch.cat([wh, wh.new_zeros(pad, wh.shape[1])], dim=0)
                 bh = torch.cat([bh, bh.new_zeros(pad)], dim=0)
-            self._branch_cache[key] = (w1, b1, w2, b2, wh, bh)
+            self._branch_cache[key] = tuple(grad_sink(t) for t in (w1, b1, w2, b2, wh, bh))
         return self._branch_cache[key]
 
     def _branch(self, feat, priors, sec: bool):

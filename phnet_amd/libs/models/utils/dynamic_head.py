@@ -3,6 +3,7 @@ import torch
 import torch.nn as nn
 
 from phnet_amd import functional as PF
+from phnet_amd.arena import grad_sink
 
 
 class DynamicConv(nn.Module):
@@ -37,7 +38,7 @@ class DynamicConv(nn.Module):
             l1, l2 = seq[0], seq[1]
             w_eff_t = PF.linear(l1.weight.t().contiguous(), l2.weight)              # [K, N] = (W2 W1)^T
             b_eff = PF.linear(l1.bias.unsqueeze(0), l2.weight, l2.bias)[0]          # W2 b1 + b2
-            self._folded[name] = (w_eff_t.t().contiguous(), b_eff.contiguous())
+            self._folded[name] = (grad_sink(w_eff_t.t().contiguous()), grad_sink(b_eff.contiguous()))
         return self._folded[name]
 
     def forward(self, pro_feature: torch.Tensor, roi_feature: torch.Tensor) -> torch.Tensor:

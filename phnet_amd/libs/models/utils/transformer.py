@@ -19,8 +19,8 @@ def _attention(mha: nn.MultiheadAttention, q_in: torch.Tensor, kv_in: torch.Tens
         qkv = PF.linear(q_in, w, b)                       # self-attention: one [L,3E] projection on the whole in_proj
         out = PF.attention_packed(qkv, h, p_drop)
     else:
-        q = PF.linear(q_in, w[:e], b[:e])
-        kv = PF.linear(kv_in, w[e:], b[e:])
+        q = PF.linear(q_in, w, b, rows=(0, e))
+        kv = PF.linear(kv_in, w, b, rows=(e, 3 * e))
         out = PF.attention_cross(q, kv, h, p_drop, key_valid)
     return PF.linear(out, mha.out_proj.weight, mha.out_proj.bias)
 

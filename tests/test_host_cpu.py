@@ -116,3 +116,33 @@ def test_compat_install_registers_reference_import_paths():
         for k in [k for k in sys.modules if k == "libs" or k.startswith("libs.")]:
             del sys.modules[k]
         sys.modules.update({k: v for k, v in saved.items() if v is not None})
+
+
+def test_grad_sink_collects_per_use_gradients_once():
+    """arena.grad_sink: uses accumulate into the side buffer and return no gradient; autograd gets the sum exactly once."""
+    from phnet_amd.arena import direct_grad, grad_sink
+
+    class Use(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w):
+            ctx.save_for_backward(x, w)
+            ctx.sink = direct_grad(w)
+            return x @ w.t()
+
+        @staticmethod
+        def backward(ctx, g):
+            x, w = ctx.saved_tensors
+            ctx.sink.add_(g.t() @ x)
+            return g @ w, None
+
+    torch.manual_seed(0)
+    a, b = torch.randn(4, 3, requires_grad=True), torch.randn(4, 3, requires_grad=True)
+    x = torch.randn(5, 3)
+    w = grad_sink(a * b)
+    assert direct_grad(w) is not None and torch.equal(w, a * b)
+    sum(Use.apply(x * (i + 1), w).sum() for i in range(3)).backward()
+    a2, b2 = a.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
+    sum(((x * (i + 1)) @ (a2 * b2).t()).sum() for i in range(3)).backward()
+    assert torch.allclose(a.grad, a2.grad) and torch.allclose(b.grad, b2.grad)
+    with torch.no_grad():
+        assert grad_sink(a * b)._phnet_sink is None if hasattr(grad_sink(a * b), "_phnet_sink") else True
