@@ -184,15 +184,30 @@ int phnet_gate_stack_bwd(const float* gout, const float* x, const float* out, co
 /* ---- fused attention core (heads of width 16, Lq/Lk <= 256): replaces the scale/bmm/mask/softmax/dropout/bmm chain inside
  * nn.MultiheadAttention (libs/models/utils/transformer.py:275-298) and its backward.  q/k/v/o and the gradients are
  * addressed with row strides (floats), heads packed along the row.  key_valid u8[Lk] optional; keep u8[H][Lq][Lk]
- * optional dropout keep-mask (kept weights scaled by keep_scale); lse [H][Lq]. ---- */
+ * optional explicit dropout keep-mask (kept weights scaled by keep_scale); with keep == NULL, rng_state != NULL and
+ * drop_p > 0 the mask is drawn in the kernel instead: element (h, q, k) of dropout site rng_call is kept iff a splitmix64
+ * hash of (*rng_state, rng_call, element index) clears drop_p * 2^32, scale 1/(1-drop_p); the backward recomputes the
+ * same bits (F.dropout inside nn.MultiheadAttention).  *rng_state is a device counter the caller bumps once per step.
+ * lse [H][Lq]. ---- */
 int phnet_attention_fwd(const float* q, const float* k, const float* v, const uint8_t* key_valid, const uint8_t* keep,
                         float* o, float* lse, int32_t Lq, int32_t Lk, int32_t H, int32_t E,
-                        int64_t sq, int64_t sk, int64_t sv, int64_t so, float keep_scale, void* stream);
+                        int64_t sq, int64_t sk, int64_t sv, int64_t so, float keep_scale,
+                        const uint64_t* rng_state, uint64_t rng_call, float drop_p, void* stream);
 int phnet_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* dout,
                         const float* lse, const uint8_t* key_valid, const uint8_t* keep,
                         float* dq, float* dk, float* dv, int32_t Lq, int32_t Lk, int32_t H, int32_t E,
                         int64_t sq, int64_t sk, int64_t sv, int64_t so, int64_t sdq, int64_t sdk, int64_t sdv,
-                        float keep_scale, void* stream);
+                        float keep_scale, const uint64_t* rng_state, uint64_t rng_call, float drop_p, void* stream);
+
+/* ---- transformer glue: `tgt + dropout(x)` and `dropout(gelu(x))` (libs/models/utils/transformer.py:275-298) as one launch
+ * each, dropout bits from the same counter-based generator as the attention kernels (site id rng_call; drop_p = 0 or
+ * rng_state = NULL: no dropout).  phnet_dropout_add with res = NULL is plain dropout, which is also its own backward. ---- */
+int phnet_dropout_add(const float* x, const float* res, float* y, int64_t n,
+                      const uint64_t* rng_state, uint64_t rng_call, float drop_p, void* stream);
+int phnet_gelu_dropout_fwd(const float* x, float* y, int64_t n, const uint64_t* rng_state, uint64_t rng_call, float drop_p,
+                           void* stream);
+int phnet_gelu_dropout_bwd(const float* dy, const float* x, float* dx, int64_t n, const uint64_t* rng_state,
+                           uint64_t rng_call, float drop_p, void* stream);
 
 /* ---- per-anchor dynamic convolution: y[n] = relu(LayerNorm_J(x[n] @ w[n]) * gamma + beta), replacing torch.bmm + norm1/norm2
  * + ReLU in libs/models/utils/dynamic_head.py:40-51 (and their backward).  x [N][P][K], w [N][K][J] (generated per anchor),

@@ -26,7 +26,7 @@ __device__ __forceinline__ float quad_max(float v) { v = fmaxf(v, __shfl_xor(v, 
 
 __global__ __launch_bounds__(NT) void attn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
                                                       const unsigned char* __restrict__ key_valid, const unsigned char* __restrict__ keep,
-                                                      float* __restrict__ o, float* __restrict__ lse, AttnShape g)
+                                                      float* __restrict__ o, float* __restrict__ lse, AttnShape g, DropRng rng)
 {
     __shared__ float Ks[MAXK][D + 1], Vs[MAXK][D + 1];
     __shared__ unsigned char valid[MAXK];
@@ -46,6 +46,7 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(const float* __restrict__ 
 #pragma unroll
     for (int d = 0; d < D; ++d) acc[d] = 0.f;
     const unsigned char* kp = keep ? keep + ((size_t)h * g.Lq + (live ? row : 0)) * g.Lk : nullptr;
+    const uint64_t seed = phnet_rng_seed(rng), rbase = ((uint64_t)h * g.Lq + (live ? row : 0)) * g.Lk;
     for (int kk = part; kk < g.Lk; kk += 4) {
         if (!valid[kk]) continue;
         float s = 0.f;
@@ -54,7 +55,8 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(const float* __restrict__ 
         const float mn = fmaxf(m, s);
         const float c = expf(m - mn), e = expf(s - mn);
         l = l * c + e;
-        const float ed = (kp && !kp[kk]) ? 0.f : e * g.keep_scale;
+        const bool kept = kp ? kp[kk] != 0 : (!rng.thresh || phnet_rng_keep(seed, rbase + kk, rng.thresh));
+        const float ed = kept ? e * g.keep_scale : 0.f;
 #pragma unroll
         for (int d = 0; d < D; ++d) acc[d] = acc[d] * c + ed * Vs[kk][d];
         m = mn;
@@ -79,8 +81,9 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(const float* __restrict__ 
                                                       const float* __restrict__ lse, const unsigned char* __restrict__ key_valid,
                                                       const unsigned char* __restrict__ keep,
                                                       float* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv,
-                                                      AttnShape g, long sdq, long sdk, long sdv, int q_tiles)
+                                                      AttnShape g, long sdq, long sdk, long sdv, int q_tiles, DropRng rng)
 {
+    const uint64_t seed = phnet_rng_seed(rng);
     __shared__ float As[MAXK][D + 1], Bs[MAXK][D + 1];     // role 0: K, V of the head; role 1: Q*scale, dO of the head
     __shared__ float Dl[MAXK], Ls[MAXK];                   // role 1: rowsum(dO*O), lse per query
     __shared__ unsigned char valid[MAXK];
@@ -107,6 +110,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(const float* __restrict__ 
         }
         const float L = lse[(size_t)h * g.Lq + r];
         const unsigned char* kp = keep ? keep + ((size_t)h * g.Lq + r) * g.Lk : nullptr;
+        const uint64_t rbase = ((uint64_t)h * g.Lq + r) * g.Lk;
         float acc[D];
 #pragma unroll
         for (int d = 0; d < D; ++d) acc[d] = 0.f;
@@ -116,7 +120,8 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(const float* __restrict__ 
 #pragma unroll
             for (int d = 0; d < D; ++d) { s += qr[d] * As[kk][d]; dp += dor[d] * Bs[kk][d]; }
             const float p = expf(s - L);
-            if (kp && !kp[kk]) dp = 0.f; else dp *= g.keep_scale;
+            const bool kept = kp ? kp[kk] != 0 : (!rng.thresh || phnet_rng_keep(seed, rbase + kk, rng.thresh));
+            dp = kept ? dp * g.keep_scale : 0.f;
             const float ds = p * (dp - delta);
 #pragma unroll
             for (int d = 0; d < D; ++d) acc[d] += ds * As[kk][d];
@@ -158,7 +163,8 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(const float* __restrict__ 
 #pragma unroll
                 for (int d = 0; d < D; ++d) { s += As[qq][d] * kr[d]; dp += Bs[qq][d] * vr[d]; }
                 const float p = expf(s - Ls[qq]);
-                const bool kept = !keep || keep[((size_t)h * g.Lq + qq) * g.Lk + r];
+                const uint64_t ei = ((uint64_t)h * g.Lq + qq) * g.Lk + r;
+                const bool kept = keep ? keep[ei] != 0 : (!rng.thresh || phnet_rng_keep(seed, ei, rng.thresh));
                 const float pd = kept ? p * g.keep_scale : 0.f;       // dropped attention weight
                 const float ds = p * ((kept ? dp * g.keep_scale : 0.f) - Dl[qq]);
 #pragma unroll
@@ -180,16 +186,19 @@ bool attn_ok(int Lq, int Lk, int H, int E) { return Lq >= 1 && Lk >= 1 && Lq <= 
 }  // namespace
 
 // q [Lq][.] row stride sq, k/v [Lk][.] row strides sk/sv (heads packed along the row: column h*16+d); o [Lq][.] stride so;
-// key_valid (optional) u8[Lk]; keep (optional, training dropout) u8[H][Lq][Lk], kept weights are scaled by keep_scale
-// = 1/(1-p); lse [H][Lq] saved for the backward.  Lq, Lk <= 256, head width 16.
+// key_valid (optional) u8[Lk]; dropout of the attention weights either by an explicit mask keep u8[H][Lq][Lk] (kept weights
+// scaled by keep_scale) or, when keep is NULL and rng_state/drop_p are given, by the counter-based mask of common.h
+// (site id rng_call, scale 1/(1-p)); lse [H][Lq] saved for the backward.  Lq, Lk <= 256, head width 16.
 PHNET_API int phnet_attention_fwd(const float* q, const float* k, const float* v, const uint8_t* key_valid, const uint8_t* keep,
                                   float* o, float* lse, int32_t Lq, int32_t Lk, int32_t H, int32_t E,
-                                  int64_t sq, int64_t sk, int64_t sv, int64_t so, float keep_scale, void* stream)
+                                  int64_t sq, int64_t sk, int64_t sv, int64_t so, float keep_scale,
+                                  const uint64_t* rng_state, uint64_t rng_call, float drop_p, void* stream)
 {
-    if (!attn_ok(Lq, Lk, H, E) || !q || !k || !v || !o || !lse) return PHNET_ERR_ARG;
-    AttnShape g{Lq, Lk, H, sq, sk, sv, so, 1.0f / sqrtf((float)D), keep ? keep_scale : 1.0f};
+    if (!attn_ok(Lq, Lk, H, E) || !q || !k || !v || !o || !lse || drop_p < 0.f || drop_p >= 1.f) return PHNET_ERR_ARG;
+    const DropRng rng = keep ? DropRng{nullptr, 0, 0u} : phnet_make_rng(rng_state, rng_call, drop_p);
+    AttnShape g{Lq, Lk, H, sq, sk, sv, so, 1.0f / sqrtf((float)D), keep ? keep_scale : (rng.thresh ? 1.0f / (1.0f - drop_p) : 1.0f)};
     hipLaunchKernelGGL(attn_fwd_kernel, dim3(H, (Lq + ROWS - 1) / ROWS), dim3(NT), 0, (hipStream_t)stream,
-                       q, k, v, key_valid, keep, o, lse, g);
+                       q, k, v, key_valid, keep, o, lse, g, rng);
     return phnet_launch_status();
 }
 
@@ -198,12 +207,14 @@ PHNET_API int phnet_attention_bwd(const float* q, const float* k, const float* v
                                   const float* lse, const uint8_t* key_valid, const uint8_t* keep,
                                   float* dq, float* dk, float* dv, int32_t Lq, int32_t Lk, int32_t H, int32_t E,
                                   int64_t sq, int64_t sk, int64_t sv, int64_t so, int64_t sdq, int64_t sdk, int64_t sdv,
-                                  float keep_scale, void* stream)
+                                  float keep_scale, const uint64_t* rng_state, uint64_t rng_call, float drop_p, void* stream)
 {
-    if (!attn_ok(Lq, Lk, H, E) || !q || !k || !v || !o || !dout || !lse || !dq || !dk || !dv) return PHNET_ERR_ARG;
-    AttnShape g{Lq, Lk, H, sq, sk, sv, so, 1.0f / sqrtf((float)D), keep ? keep_scale : 1.0f};
+    if (!attn_ok(Lq, Lk, H, E) || !q || !k || !v || !o || !dout || !lse || !dq || !dk || !dv || drop_p < 0.f || drop_p >= 1.f)
+        return PHNET_ERR_ARG;
+    const DropRng rng = keep ? DropRng{nullptr, 0, 0u} : phnet_make_rng(rng_state, rng_call, drop_p);
+    AttnShape g{Lq, Lk, H, sq, sk, sv, so, 1.0f / sqrtf((float)D), keep ? keep_scale : (rng.thresh ? 1.0f / (1.0f - drop_p) : 1.0f)};
     const int qt = (Lq + ROWS - 1) / ROWS, kt = (Lk + ROWS - 1) / ROWS;
     hipLaunchKernelGGL(attn_bwd_kernel, dim3(H, qt + kt), dim3(NT), 0, (hipStream_t)stream,
-                       q, k, v, o, dout, lse, key_valid, keep, dq, dk, dv, g, (long)sdq, (long)sdk, (long)sdv, qt);
+                       q, k, v, o, dout, lse, key_valid, keep, dq, dk, dv, g, (long)sdq, (long)sdk, (long)sdv, qt, rng);
     return phnet_launch_status();
 }

@@ -26,4 +26,28 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// ---- counter-based dropout masks --------------------------------------------------------------------------------
+// A training step owns one 64-bit device counter (bumped once per step, so a replayed hipGraph draws fresh masks); each
+// dropout site of the step has a host-side call id.  Element idx of site `call` is kept iff the splitmix64 finaliser of
+// (state, call, idx) clears the threshold p * 2^32 - the backward kernels recompute the same bit instead of reading a
+// stored mask.
+struct DropRng { const uint64_t* state; uint64_t call; uint32_t thresh; };
+
+__device__ __forceinline__ uint64_t phnet_mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ uint64_t phnet_rng_seed(const DropRng& r) {
+    return r.thresh ? phnet_mix64(r.state[0] * 0xD1342543DE82EF95ull + r.call) : 0ull;       // one stream per (step, site)
+}
+__device__ __forceinline__ bool phnet_rng_keep(uint64_t seed, uint64_t idx, uint32_t thresh) {
+    return (uint32_t)(phnet_mix64(seed + (idx + 1) * 0x9E3779B97F4A7C15ull) >> 32) >= thresh;
+}
+static inline DropRng phnet_make_rng(const uint64_t* state, uint64_t call, float p) {
+    DropRng r{state, call, 0u};
+    if (state && p > 0.f) r.thresh = (uint32_t)fmin(4294967295.0, (double)p * 4294967296.0);
+    return r;
+}
+
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }

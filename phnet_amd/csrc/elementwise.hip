@@ -10,6 +10,42 @@ __global__ __launch_bounds__(NT) void relu_bwd_kernel(const float* __restrict__ 
     const long i = (long)blockIdx.x * NT + threadIdx.x;
     if (i < n) dx[i] = y[i] > 0.f ? dy[i] : 0.f;
 }
+
+// ---- transformer glue (utils/transformer.py:275-298): residual + dropout, GELU + dropout ------------------------------
+// y = res + drop(x);   MODE 1: dx = drop'(dy) (the residual's gradient is dy itself)
+__global__ __launch_bounds__(NT) void dropout_add_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                         float* __restrict__ y, long n, DropRng rng, float scale)
+{
+    const long i = (long)blockIdx.x * NT + threadIdx.x;
+    if (i >= n) return;
+    const bool kept = !rng.thresh || phnet_rng_keep(phnet_rng_seed(rng), (uint64_t)i, rng.thresh);
+    const float v = kept ? x[i] * scale : 0.f;
+    y[i] = res ? res[i] + v : v;
+}
+
+__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_grad(float v) {
+    return 0.5f * (1.0f + erff(v * 0.70710678118654752f)) + v * 0.39894228040143268f * expf(-0.5f * v * v);
+}
+
+// y = drop(gelu(x));  backward: dx = drop'(dy) * gelu'(x)
+__global__ __launch_bounds__(NT) void gelu_dropout_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long n,
+                                                              DropRng rng, float scale)
+{
+    const long i = (long)blockIdx.x * NT + threadIdx.x;
+    if (i >= n) return;
+    const bool kept = !rng.thresh || phnet_rng_keep(phnet_rng_seed(rng), (uint64_t)i, rng.thresh);
+    y[i] = kept ? gelu_erf(x[i]) * scale : 0.f;
+}
+__global__ __launch_bounds__(NT) void gelu_dropout_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                              float* __restrict__ dx, long n, DropRng rng, float scale)
+{
+    const long i = (long)blockIdx.x * NT + threadIdx.x;
+    if (i >= n) return;
+    const bool kept = !rng.thresh || phnet_rng_keep(phnet_rng_seed(rng), (uint64_t)i, rng.thresh);
+    dx[i] = kept ? dy[i] * scale * gelu_erf_grad(x[i]) : 0.f;
+}
+
 // ---- lane prior update (Router4OL.py:328-345): one thread per anchor ------------------------------------------
 // head [N][HW] = (cls 2 | reg 4 | offsets S | pad); priors [N][6+S]; ys [S] = prior_ys
 // lines = (cls, start_y/start_x/theta + tanh(reg[:3]), reg[3], xs(line));  preds = lines with xs + offsets
@@ -113,5 +149,44 @@ PHNET_API int phnet_relu_bwd(const float* dy, const float* y, float* dx, int64_t
     if (n == 0) return PHNET_OK;
     if (!dy || !y || !dx) return PHNET_ERR_ARG;
     hipLaunchKernelGGL(relu_bwd_kernel, dim3((unsigned)ceil_div64(n, NT)), dim3(NT), 0, (hipStream_t)stream, dy, y, dx, (long)n);
+    return phnet_launch_status();
+}
+
+// y = res + dropout(x) (res may be NULL: plain dropout; drop_p = 0: plain residual add).  The mask of element i is the
+// counter-based bit of common.h for site rng_call; calling again with x = dy, res = NULL gives the backward.
+PHNET_API int phnet_dropout_add(const float* x, const float* res, float* y, int64_t n,
+                                const uint64_t* rng_state, uint64_t rng_call, float drop_p, void* stream)
+{
+    if (n < 0 || drop_p < 0.f || drop_p >= 1.f) return PHNET_ERR_ARG;
+    if (n == 0) return PHNET_OK;
+    if (!x || !y) return PHNET_ERR_ARG;
+    const DropRng rng = phnet_make_rng(rng_state, rng_call, drop_p);
+    hipLaunchKernelGGL(dropout_add_kernel, dim3((unsigned)ceil_div64(n, NT)), dim3(NT), 0, (hipStream_t)stream, x, res, y, (long)n, rng,
+                       rng.thresh ? 1.0f / (1.0f - drop_p) : 1.0f);
+    return phnet_launch_status();
+}
+
+// y = dropout(gelu(x)) with the exact (erf) GELU of F.gelu; backward dx = dropout'(dy) * gelu'(x) with the same mask bits.
+PHNET_API int phnet_gelu_dropout_fwd(const float* x, float* y, int64_t n, const uint64_t* rng_state, uint64_t rng_call, float drop_p,
+                                     void* stream)
+{
+    if (n < 0 || drop_p < 0.f || drop_p >= 1.f) return PHNET_ERR_ARG;
+    if (n == 0) return PHNET_OK;
+    if (!x || !y) return PHNET_ERR_ARG;
+    const DropRng rng = phnet_make_rng(rng_state, rng_call, drop_p);
+    hipLaunchKernelGGL(gelu_dropout_fwd_kernel, dim3((unsigned)ceil_div64(n, NT)), dim3(NT), 0, (hipStream_t)stream, x, y, (long)n, rng,
+                       rng.thresh ? 1.0f / (1.0f - drop_p) : 1.0f);
+    return phnet_launch_status();
+}
+
+PHNET_API int phnet_gelu_dropout_bwd(const float* dy, const float* x, float* dx, int64_t n, const uint64_t* rng_state,
+                                     uint64_t rng_call, float drop_p, void* stream)
+{
+    if (n < 0 || drop_p < 0.f || drop_p >= 1.f) return PHNET_ERR_ARG;
+    if (n == 0) return PHNET_OK;
+    if (!dy || !x || !dx) return PHNET_ERR_ARG;
+    const DropRng rng = phnet_make_rng(rng_state, rng_call, drop_p);
+    hipLaunchKernelGGL(gelu_dropout_bwd_kernel, dim3((unsigned)ceil_div64(n, NT)), dim3(NT), 0, (hipStream_t)stream, dy, x, dx, (long)n,
+                       rng, rng.thresh ? 1.0f / (1.0f - drop_p) : 1.0f);
     return phnet_launch_status();
 }

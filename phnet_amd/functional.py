@@ -248,6 +248,81 @@ def lane_update(priors, head, ys, img_w, img_h):
     return _LaneUpdate.apply(priors, head, ys, img_w, img_h)
 
 
+class DropoutStream:
+    """Counter-based dropout masks (csrc/common.h): int64 device counters bumped once per training step, and a host-side id
+    per dropout site of the step.  Kernels hash (counter, site, element) - no mask tensors, no RNG launches, and a
+    replayed hipGraph still draws fresh masks because the counter bump is part of the captured step.  The counters form a
+    ring of SLOTS (slot s only ever holds values = s mod SLOTS), so the masks of a forward stay reproducible for its
+    backward even if up to SLOTS-1 further forwards run in between."""
+    SLOTS = 8
+    _state = {}
+    _slot = {}
+    _calls = 0
+
+    @classmethod
+    def _ring(cls, device) -> torch.Tensor:
+        key = torch.device(device).index
+        if key not in cls._state:
+            base = (torch.initial_seed() & 0xFFFFFFFFFFFF) * cls.SLOTS
+            cls._state[key] = torch.arange(cls.SLOTS, dtype=torch.int64, device=device) + base
+            cls._slot[key] = 0
+        return cls._state[key]
+
+    @classmethod
+    def begin_step(cls, device):
+        ring, key = cls._ring(device), torch.device(device).index
+        cls._slot[key] = (cls._slot[key] + 1) % cls.SLOTS
+        ring[cls._slot[key]:cls._slot[key] + 1].add_(cls.SLOTS)
+        cls._calls = 0
+
+    @classmethod
+    def site(cls, device, p: float):
+        """rng triple (counter view, site id, p) for one dropout site, or None when p == 0."""
+        if p <= 0.0:
+            return None
+        ring, key = cls._ring(device), torch.device(device).index
+        cls._calls += 1
+        return ring[cls._slot[key]:cls._slot[key] + 1], cls._calls, float(p)
+
+
+class _DropoutAdd(torch.autograd.Function):
+    """res + dropout(x) as one launch (transformer residuals); p = 0 is a plain residual add."""
+
+    @staticmethod
+    def forward(ctx, res, x, p):
+        ctx.rng = DropoutStream.site(x.device, p)
+        return K.dropout_add(x.contiguous(), res.contiguous(), ctx.rng)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dx = dy if ctx.rng is None else K.dropout_add(dy.contiguous(), None, ctx.rng)
+        return dy, dx, None
+
+
+def dropout_add(res, x, p: float = 0.0):
+    return _DropoutAdd.apply(res, x, p)
+
+
+class _GeluDropout(torch.autograd.Function):
+    """dropout(gelu(x)), exact (erf) GELU, one launch each way."""
+
+    @staticmethod
+    def forward(ctx, x, p):
+        xc = x.contiguous()
+        ctx.rng = DropoutStream.site(x.device, p)
+        ctx.save_for_backward(xc)
+        return K.gelu_dropout_fwd(xc, ctx.rng)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return K.gelu_dropout_bwd(dy.contiguous(), x, ctx.rng), None
+
+
+def gelu_dropout(x, p: float = 0.0):
+    return _GeluDropout.apply(x, p)
+
+
 class _Attention(torch.autograd.Function):
     """softmax(q k^T / sqrt(d)) v per head on the fused HIP kernels.  `packed` is either the [L,3E] output of the
     self-attention projection (q|k|v column blocks) or None; otherwise q [Lq,E] and kv [M,2E] (k|v) are separate.
@@ -262,19 +337,16 @@ class _Attention(torch.autograd.Function):
         else:
             kv_in = kv_in.contiguous()
             q, k, v = q_in, kv_in[:, :e], kv_in[:, e:]
-        keep, scale = None, 1.0
-        if dropout_p > 0.0:
-            keep = (torch.rand((heads, q.shape[0], k.shape[0]), device=q.device) >= dropout_p).to(torch.uint8)
-            scale = 1.0 / (1.0 - dropout_p)
+        rng = DropoutStream.site(q.device, dropout_p)          # attention-weight dropout drawn inside the kernels
         kvu8 = None if key_valid is None else key_valid.to(torch.uint8).contiguous()
-        out, lse = K.attention_fwd(q, k, v, heads, kvu8, keep, scale)
-        ctx.save_for_backward(q_in, kv_in, out, lse, kvu8, keep)
-        ctx.heads, ctx.scale, ctx.e = heads, scale, e
+        out, lse = K.attention_fwd(q, k, v, heads, kvu8, rng=rng)
+        ctx.save_for_backward(q_in, kv_in, out, lse, kvu8)
+        ctx.heads, ctx.rng, ctx.e = heads, rng, e
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        q_in, kv_in, out, lse, kvu8, keep = ctx.saved_tensors
+        q_in, kv_in, out, lse, kvu8 = ctx.saved_tensors
         e = ctx.e
         dq_in = torch.empty_like(q_in)
         if kv_in is None:
@@ -285,7 +357,7 @@ class _Attention(torch.autograd.Function):
             dkv_in = torch.empty_like(kv_in)
             q, k, v = q_in, kv_in[:, :e], kv_in[:, e:]
             dq, dk, dv = dq_in, dkv_in[:, :e], dkv_in[:, e:]
-        K.attention_bwd(q, k, v, out, dout.contiguous(), lse, ctx.heads, dq, dk, dv, kvu8, keep, ctx.scale)
+        K.attention_bwd(q, k, v, out, dout.contiguous(), lse, ctx.heads, dq, dk, dv, kvu8, rng=ctx.rng)
         return None, None, None, dq_in, dkv_in
 
 

@@ -516,27 +516,58 @@ def gate_stack_bwd(gout, x, out, params, saved, grads, eps: float, accumulate: b
                                      n, c, p, eps, int(accumulate), _ptr(ws), ws.numel(), _stream()), "phnet_gate_stack_bwd")
 
 
-def attention_fwd(q, k, v, heads: int, key_valid=None, keep=None, keep_scale: float = 1.0):
-    """q [Lq,E], k/v [Lk,E] (any row stride, unit column stride) -> (o [Lq,E], lse [H,Lq])."""
+def _rng_args(rng):
+    """rng = None | (state int64[1] device tensor, call id, drop probability) -> the three C arguments."""
+    if rng is None:
+        return None, 0, 0.0
+    state, call, p = rng
+    return _ptr(state), int(call), float(p)
+
+
+def attention_fwd(q, k, v, heads: int, key_valid=None, keep=None, keep_scale: float = 1.0, rng=None):
+    """q [Lq,E], k/v [Lk,E] (any row stride, unit column stride) -> (o [Lq,E], lse [H,Lq]).  Dropout of the attention
+    weights: explicit `keep` u8[H,Lq,Lk] (+ keep_scale), or `rng` for the in-kernel counter-based mask."""
     lq, e = q.shape
     lk = k.shape[0]
     assert q.stride(1) == 1 and k.stride(1) == 1 and v.stride(1) == 1
     out = torch.empty((lq, e), dtype=torch.float32, device=q.device)
     lse = torch.empty((heads, lq), dtype=torch.float32, device=q.device)
     check(lib().phnet_attention_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(key_valid), _ptr(keep), _ptr(out), _ptr(lse), lq, lk, heads, e,
-                                    q.stride(0), k.stride(0), v.stride(0), out.stride(0), float(keep_scale), _stream()),
+                                    q.stride(0), k.stride(0), v.stride(0), out.stride(0), float(keep_scale), *_rng_args(rng), _stream()),
           "phnet_attention_fwd")
     return out, lse
 
 
-def attention_bwd(q, k, v, o, dout, lse, heads: int, dq, dk, dv, key_valid=None, keep=None, keep_scale: float = 1.0):
+def attention_bwd(q, k, v, o, dout, lse, heads: int, dq, dk, dv, key_valid=None, keep=None, keep_scale: float = 1.0, rng=None):
     """Writes dq/dk/dv (views with arbitrary row stride)."""
     lq, e = q.shape
     lk = k.shape[0]
     check(lib().phnet_attention_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(dout), _ptr(lse), _ptr(key_valid), _ptr(keep),
                                     _ptr(dq), _ptr(dk), _ptr(dv), lq, lk, heads, e, q.stride(0), k.stride(0), v.stride(0),
-                                    o.stride(0), dq.stride(0), dk.stride(0), dv.stride(0), float(keep_scale), _stream()),
-          "phnet_attention_bwd")
+                                    o.stride(0), dq.stride(0), dk.stride(0), dv.stride(0), float(keep_scale), *_rng_args(rng),
+                                    _stream()), "phnet_attention_bwd")
+
+
+def dropout_add(x, res=None, rng=None):
+    """res + dropout(x) (either part optional) in one launch; dropout_add(dy, None, rng) is the backward of the dropout."""
+    _req(x, name="x")
+    y = torch.empty_like(x)
+    check(lib().phnet_dropout_add(_ptr(x), _ptr(res), _ptr(y), x.numel(), *_rng_args(rng), _stream()), "phnet_dropout_add")
+    return y
+
+
+def gelu_dropout_fwd(x, rng=None):
+    _req(x, name="x")
+    y = torch.empty_like(x)
+    check(lib().phnet_gelu_dropout_fwd(_ptr(x), _ptr(y), x.numel(), *_rng_args(rng), _stream()), "phnet_gelu_dropout_fwd")
+    return y
+
+
+def gelu_dropout_bwd(dy, x, rng=None):
+    _req(dy, name="dy")
+    dx = torch.empty_like(x)
+    check(lib().phnet_gelu_dropout_bwd(_ptr(dy), _ptr(x), _ptr(dx), x.numel(), *_rng_args(rng), _stream()), "phnet_gelu_dropout_bwd")
+    return dx
 
 
 def lane_decode(lines, conf_thresh: float, nms_thresh: float, top_k: int, img_w: int):

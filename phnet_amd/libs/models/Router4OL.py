@@ -318,6 +318,8 @@ class RouterOL(nn.Module):
             return self.lanes_from_device(rows, nums)
         T = frame.shape[0]
         self._begin_clip()
+        if self.training:
+            PF.DropoutStream.begin_step(frame.device)                          # fresh dropout masks for this clip's fwd + bwd
         feats = self.backbone(frame)                                           # 3 x [T,h,w,C] NHWC
         last_cuts = []
         total_loss = 0.0

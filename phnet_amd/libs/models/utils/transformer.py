@@ -5,7 +5,6 @@ import math
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from phnet_amd import functional as PF
 
@@ -41,13 +40,14 @@ class TransformerDecoderLayer(nn.Module):
 
     def forward(self, tgt: torch.Tensor, memory: torch.Tensor, memory_key_valid=None) -> torch.Tensor:
         """tgt [L,E], memory [M,E], memory_key_valid bool[M] or None."""
+        p = lambda d: d.p if self.training else 0.0                                  # noqa: E731
         h = PF.layer_norm(tgt, self.norm1.weight, self.norm1.bias, eps=self.norm1.eps)
-        tgt = tgt + self.dropout1(_attention(self.self_attn, h, h, self.training))
+        tgt = PF.dropout_add(tgt, _attention(self.self_attn, h, h, self.training), p(self.dropout1))
         h = PF.layer_norm(tgt, self.norm2.weight, self.norm2.bias, eps=self.norm2.eps)
-        tgt = tgt + self.dropout2(_attention(self.multihead_attn, h, memory, self.training, memory_key_valid))
+        tgt = PF.dropout_add(tgt, _attention(self.multihead_attn, h, memory, self.training, memory_key_valid), p(self.dropout2))
         h = PF.layer_norm(tgt, self.norm3.weight, self.norm3.bias, eps=self.norm3.eps)
-        h = self.dropout(F.gelu(PF.linear(h, self.linear1.weight, self.linear1.bias)))
-        return tgt + self.dropout3(PF.linear(h, self.linear2.weight, self.linear2.bias))
+        h = PF.gelu_dropout(PF.linear(h, self.linear1.weight, self.linear1.bias), p(self.dropout))
+        return PF.dropout_add(tgt, PF.linear(h, self.linear2.weight, self.linear2.bias), p(self.dropout3))
 
 
 class TransformerDecoder(nn.Module):

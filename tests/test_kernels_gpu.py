@@ -399,6 +399,77 @@ def test_fused_attention_fwd_bwd(ops, Lq, Lk, masked, drop):
         close(dpk[:, :E], q.grad, 5e-5); close(dpk[:, E:2 * E], k.grad, 5e-5); close(dpk[:, 2 * E:], v.grad, 5e-5)
 
 
+def _rng(state_value, call, p):
+    return (torch.tensor([state_value], dtype=torch.int64, device="cuda"), call, p)
+
+
+def test_attention_in_kernel_dropout_matches_explicit_mask(ops):
+    """The counter-based dropout of the attention kernels: recover the mask it drew (one-hot V exposes the dropped attention
+    weights), then the explicit-mask path - itself checked against torch above - must reproduce forward and backward."""
+    torch.manual_seed(5)
+    H, E, Lq, Lk, p = 8, 128, 240, 16, 0.25
+    q, k = torch.randn(Lq, E, device="cuda"), torch.randn(Lk, E, device="cuda")
+    onehot = torch.eye(16, device="cuda").repeat(1, H).contiguous()                  # V[k, h*16+d] = (k == d)
+    rng = _rng(123456789, 7, p)
+    probe, _ = ops.attention_fwd(q, k, onehot, H, rng=rng)                           # probe[q, h*16+k] = dropped weight (h,q,k)
+    keep = (probe.view(Lq, H, Lk) > 0).permute(1, 0, 2).contiguous().to(torch.uint8)
+    frac = float(keep.float().mean())
+    assert abs(frac - (1 - p)) < 0.02, frac
+    per_head = keep.float().mean(dim=(1, 2))
+    assert float((per_head - (1 - p)).abs().max()) < 0.05
+    v, g = torch.randn(Lk, E, device="cuda"), torch.randn(Lq, E, device="cuda")
+    o1, l1 = ops.attention_fwd(q, k, v, H, rng=rng)
+    o2, l2 = ops.attention_fwd(q, k, v, H, None, keep, 1.0 / (1.0 - p))
+    assert torch.equal(o1, o2) and torch.equal(l1, l2)
+    grads = []
+    for kw in (dict(rng=rng), dict(keep=keep, keep_scale=1.0 / (1.0 - p))):
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        ops.attention_bwd(q, k, v, o1, g, l1, H, dq, dk, dv, **kw)
+        grads.append((dq, dk, dv))
+    for a, b in zip(*grads):
+        assert torch.equal(a, b)
+    # another step counter or another site id draws another mask; p = 0 draws none
+    o3, _ = ops.attention_fwd(q, k, v, H, rng=_rng(123456790, 7, p))
+    o4, _ = ops.attention_fwd(q, k, v, H, rng=_rng(123456789, 8, p))
+    o5, _ = ops.attention_fwd(q, k, v, H, rng=_rng(123456789, 7, 0.0))
+    o6, _ = ops.attention_fwd(q, k, v, H)
+    assert not torch.equal(o1, o3) and not torch.equal(o1, o4) and torch.equal(o5, o6)
+
+
+@pytest.mark.parametrize("p", [0.0, 0.1, 0.5])
+def test_dropout_add_and_gelu_dropout(ops, p):
+    """res + dropout(x) and dropout(gelu(x)) (transformer.py:275-298): exact at p = 0, and at p > 0 the forward and backward
+    masks agree, the keep rate is 1-p and kept values carry the 1/(1-p) scale."""
+    torch.manual_seed(11)
+    n = 240 * 256
+    x, res, dy = (torch.randn(n, device="cuda") for _ in range(3))
+    rng = _rng(42, 3, p) if p > 0 else None
+    y = ops.dropout_add(x, res, rng)
+    d = y - res
+    kept = d != 0
+    if p == 0:
+        assert torch.equal(y, res + x)
+    else:
+        assert abs(float(kept.float().mean()) - (1 - p)) < 0.01
+        close(d[kept], x[kept] / (1 - p), 1e-6)
+        dx = ops.dropout_add(dy, None, rng)
+        assert torch.equal(dx != 0, kept)
+        close(dx[kept], dy[kept] / (1 - p), 1e-6)
+        assert not torch.equal(ops.dropout_add(x, res, _rng(43, 3, p)), y)
+    xg = x.double().cpu().requires_grad_(True)
+    ref = F.gelu(xg)
+    ref.backward(dy.double().cpu())
+    yg = ops.gelu_dropout_fwd(x, rng)
+    dxg = ops.gelu_dropout_bwd(dy, x, rng)
+    if p == 0:
+        close(yg, ref, 1e-6); close(dxg, xg.grad, 1e-6)
+    else:
+        m = ops.dropout_add(torch.ones_like(x), None, rng) != 0                      # same site -> same bits
+        close(yg[m], (ref.detach() / (1 - p)).float().cuda()[m], 1e-6)
+        close(dxg[m], (xg.grad / (1 - p)).float().cuda()[m], 1e-6)
+        assert float(yg[~m].abs().max()) == 0.0 and float(dxg[~m].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("seed,thr", [(0, 0.5), (1, 0.5), (2, 0.9), (3, 0.999999), (4, 0.0)])
 def test_lane_decode_matches_oracle_decode(ops, seed, thr):
     """Fused decode vs the oracle's decode_frame (softmax threshold + NMS rows + oracle NMS + gather)."""
