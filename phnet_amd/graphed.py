@@ -3,7 +3,11 @@
 The per-clip step is ~20 000 small launches (15 serial stage iterations); replaying them from a hipGraph removes the
 host from the loop.  Works because the training path is shape-static and sync-free (device-side label assignment,
 fixed-capacity memory tokens).  With data parallelism the gradient all-reduce runs eagerly between two graphs
-(forward+backward | optimizer)."""
+(forward+backward | optimizer).
+
+Capture caveat (PyTorch, not ours): autograd graphs of earlier EAGER steps on the default stream must be dead before a
+step is captured - a loss / gradient tensor that is still referenced keeps AccumulateGrad nodes bound to the default
+stream and the capture faults.  Build the graphed step first, or drop those references before building it."""
 from typing import Callable, Optional
 
 import torch

@@ -284,6 +284,62 @@ def test_graph_replay_reproduces_eager_steps():
         assert abs(x - y) <= (1e-4 if i == 0 else 1e-2) * abs(x), (a, b)
 
 
+def test_dropout_masks_advance_with_each_graph_replay_and_match_between_forward_and_backward():
+    """Training-mode dropout (p = 0.1, as the reference trains): (a) the backward of a step redraws exactly the forward's
+    masks - the analytic directional derivative agrees with a central difference taken with the dropout counters pinned;
+    (b) every replay of a captured step bumps the device counter, i.e. draws fresh masks."""
+    from phnet_amd import functional as PF
+    from phnet_amd.graphed import GraphedTrainStep
+    g = O.Geometry(img_h=64, img_w=160, arch="resnet18")
+    T = 3
+    frames, lanes = synth.make_clip(g, T, seed=5).cuda(), synth.make_targets(g, T).cuda()
+    from phnet_amd.config import make_cfg
+    from phnet_amd.libs.models.Router4OL import RouterOL
+    from phnet_amd.libs.utils.loss4OLV3 import Criterion4OL
+    cfg = make_cfg(img_h=g.img_h, img_w=g.img_w, arch=g.arch)
+    model = RouterOL(cfg, Criterion4OL(cfg))
+    model.load_state_dict(synth.make_state(g), strict=True)
+    model = model.cuda().train()                                   # dropout stays at the reference's 0.1
+    ring = PF.DropoutStream._ring(frames.device)
+    # (b) first: eager autograd on the default stream would leave AccumulateGrad nodes that break a later capture
+    opt = torch.optim.SGD(model.parameters(), lr=0.0)
+    step = GraphedTrainStep(model, opt, frames, lanes, warmup=1)
+    before = int(ring.sum())
+    l1 = float(step(frames)); mid = int(ring.sum()); l2 = float(step(frames))
+    assert mid - before == PF.DropoutStream.SLOTS and int(ring.sum()) - mid == PF.DropoutStream.SLOTS
+    assert l1 != l2                                               # lr = 0: only the masks differ between the two replays
+    del step
+    # (a)
+    dec = model.detNet.transformer_Dec                             # no stop-gradients inside: finite differences are valid here
+    torch.manual_seed(3)
+    tgt = torch.randn(240, 1, 128, device="cuda")
+    mem, valid = torch.randn(24, 1, 128, device="cuda"), torch.ones(24, dtype=torch.bool, device="cuda")
+    valid[5:9] = False
+    proj = torch.randn(240, 1, 128, device="cuda") / 128
+
+    def loss_with_pinned_masks(snapshot):
+        ring.copy_(snapshot)
+        PF.DropoutStream._slot[frames.device.index] = 0
+        PF.DropoutStream.begin_step(frames.device)
+        return (dec(tgt=tgt, memory=mem, memory_key_valid=valid) * proj).sum()
+
+    snap = ring.clone()
+    for w in (dec.layers[0].linear1.weight, dec.layers[0].self_attn.in_proj_weight, dec.layers[1].multihead_attn.in_proj_weight):
+        loss = loss_with_pinned_masks(snap)
+        (gw,) = torch.autograd.grad(loss, w)
+        d = gw / gw.norm()
+        eps = 1e-2
+        with torch.no_grad():
+            w.add_(eps * d); lp = float(loss_with_pinned_masks(snap))
+            w.sub_(2 * eps * d); lm = float(loss_with_pinned_masks(snap))
+            w.add_(eps * d)
+        fd, an = (lp - lm) / (2 * eps), float(gw.norm())
+        assert abs(fd - an) <= 0.02 * an + 1e-4, (fd, an)
+    # with another mask draw the output moves: the masks are really on
+    with torch.no_grad():
+        assert float(loss_with_pinned_masks(snap + 8)) != float(loss_with_pinned_masks(snap))
+
+
 def test_arena_direct_accumulation_equals_autograd_accumulation():
     """Gradients accumulated by the HIP kernels straight into the flat arena == autograd's own accumulation."""
     from phnet_amd.arena import GradArena
