@@ -209,6 +209,19 @@ int phnet_gelu_dropout_fwd(const float* x, float* y, int64_t n, const uint64_t* 
 int phnet_gelu_dropout_bwd(const float* dy, const float* x, float* dx, int64_t n, const uint64_t* rng_state,
                            uint64_t rng_call, float drop_p, void* stream);
 
+/* ---- small fused pieces of the per-frame loop ----
+ * memory tokens (Router4OL.py:563-584, _tokens): rows i64[L] = positive anchors ascending, -1 padded; tokens [L+1][E] = their
+ *   features, then the mean of all other anchors; valid u8[L+1].
+ * gate tail (Router.py:76-80): gate = sigmoid(relu(h . w + b)) and its backward from the saved output.
+ * stage hand-over (Router4OL.py:298-302): blended priors and their sampled x positions. ---- */
+int phnet_memory_tokens(const float* feat, const int64_t* rows, float* tokens, uint8_t* valid,
+                        int32_t N, int32_t E, int32_t L, void* stream);
+int phnet_gate_tail_fwd(const float* h, const float* w, const float* b, float* out, int32_t N, int32_t K, void* stream);
+int phnet_gate_tail_bwd(const float* dout, const float* out, const float* h, const float* w, float* dh, float* dw, float* db,
+                        int32_t N, int32_t K, int32_t accumulate, void* stream);
+int phnet_blend_priors(const float* gate, const float* a, const float* b, const int64_t* idx, float* priors, float* on_map,
+                       int32_t N, int32_t W, int32_t P, void* stream);
+
 /* ---- per-anchor dynamic convolution: y[n] = relu(LayerNorm_J(x[n] @ w[n]) * gamma + beta), replacing torch.bmm + norm1/norm2
  * + ReLU in libs/models/utils/dynamic_head.py:40-51 (and their backward).  x [N][P][K], w [N][K][J] (generated per anchor),
  * y [N][P][J], stats [N][P][2] = (mean, rstd) (NULL = inference).  J <= 128; J and K divide 256.  Backward: dx optional,

@@ -46,6 +46,99 @@ __global__ __launch_bounds__(NT) void gelu_dropout_bwd_kernel(const float* __res
     dx[i] = kept ? dy[i] * scale * gelu_erf_grad(x[i]) : 0.f;
 }
 
+// ---- cross-frame memory tokens (Router4OL.py:563-584): the positives' features in prior-index order, then the mean of
+// all other anchors.  rows i64[L] ascending anchor ids, -1 padded; tokens [L+1][E]; valid u8[L+1] ------------------------
+__global__ __launch_bounds__(1024) void memory_tokens_kernel(const float* __restrict__ feat, const long long* __restrict__ rows,
+                                                             float* __restrict__ tokens, unsigned char* __restrict__ valid,
+                                                             int N, int E, int L)
+{
+    extern __shared__ float part[];                  // [groups][E]
+    const int e = threadIdx.x % E, grp = threadIdx.x / E, groups = blockDim.x / E;
+    float s = 0.f;
+    if (grp < groups)
+        for (int n = grp; n < N; n += groups) s += feat[(size_t)n * E + e];
+    if (grp < groups) part[grp * E + e] = s;
+    __syncthreads();
+    if (grp != 0) return;
+    float total = 0.f;
+    for (int g2 = 0; g2 < groups; ++g2) total += part[g2 * E + e];
+    float possum = 0.f;
+    int cnt = 0;
+    for (int l = 0; l < L; ++l) {
+        const long long r = rows[l];
+        const bool ok = r >= 0 && r < N;
+        const float v = ok ? feat[(size_t)r * E + e] : 0.f;
+        tokens[(size_t)l * E + e] = v;
+        possum += v;
+        cnt += ok;
+        if (e == 0) valid[l] = ok;
+    }
+    tokens[(size_t)L * E + e] = (total - possum) / (float)(N - cnt);
+    if (e == 0) valid[L] = 1;
+}
+
+// ---- routing-gate tail (Router.py:76-80): gate = sigmoid(relu(h . w + b)), one wavefront per anchor ------------------------
+__global__ __launch_bounds__(NT) void gate_tail_fwd_kernel(const float* __restrict__ h, const float* __restrict__ w,
+                                                           const float* __restrict__ b, float* __restrict__ out, int N, int K)
+{
+    const int row = blockIdx.x * (NT / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= N) return;
+    float s = 0.f;
+    for (int k = lane; k < K; k += 64) s += h[(size_t)row * K + k] * w[k];
+    s = wave_sum(s) + b[0];
+    if (lane == 0) out[row] = 1.0f / (1.0f + expf(-fmaxf(s, 0.f)));
+}
+
+// dpre_n = dout_n * out_n (1 - out_n) where the ReLU was open (out_n > 0.5);  dh = dpre (x) w,  dw += sum_n dpre_n h_n,
+// db += sum_n dpre_n.  One thread per column k, all anchors in a loop (coalesced along k).
+__global__ __launch_bounds__(NT) void gate_tail_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out,
+                                                           const float* __restrict__ h, const float* __restrict__ w,
+                                                           float* __restrict__ dh, float* __restrict__ dw, float* __restrict__ db,
+                                                           int N, int K, int accumulate)
+{
+    __shared__ float g[1024];
+    for (int n = threadIdx.x; n < N; n += NT) {
+        const float o = out[n];
+        g[n] = o > 0.5f ? dout[n] * o * (1.0f - o) : 0.f;
+    }
+    __syncthreads();
+    const int k = blockIdx.x * NT + threadIdx.x;
+    if (k < K) {
+        const float wk = w[k];
+        float acc = 0.f;
+#pragma unroll 8
+        for (int n = 0; n < N; ++n) {
+            const float gn = g[n];
+            acc += gn * h[(size_t)n * K + k];
+            if (dh) dh[(size_t)n * K + k] = gn * wk;
+        }
+        dw[k] = accumulate ? dw[k] + acc : acc;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 64) {
+        float s = 0.f;
+        for (int n = threadIdx.x; n < N; n += 64) s += g[n];
+        s = wave_sum(s);
+        if (threadIdx.x == 0) db[0] = accumulate ? db[0] + s : s;
+    }
+}
+
+// ---- stage hand-over (Router4OL.py:298-302): priors' = (1-g) lines_a + g lines_b,  on_map = priors'[:, 6 + idx] ---------------
+__global__ __launch_bounds__(NT) void blend_priors_kernel(const float* __restrict__ gate, const float* __restrict__ a,
+                                                          const float* __restrict__ b, const long long* __restrict__ idx,
+                                                          float* __restrict__ priors, float* __restrict__ on_map, int N, int W, int P)
+{
+    const int i = blockIdx.x * NT + threadIdx.x;
+    if (i < N * W) {
+        const float gt = gate[i / W];
+        priors[i] = (1.0f - gt) * a[i] + gt * b[i];
+    }
+    if (i < N * P) {
+        const int n = i / P, c = 6 + (int)idx[i - n * P];
+        const float gt = gate[n];
+        on_map[i] = (1.0f - gt) * a[(size_t)n * W + c] + gt * b[(size_t)n * W + c];
+    }
+}
+
 // ---- lane prior update (Router4OL.py:328-345): one thread per anchor ------------------------------------------
 // head [N][HW] = (cls 2 | reg 4 | offsets S | pad); priors [N][6+S]; ys [S] = prior_ys
 // lines = (cls, start_y/start_x/theta + tanh(reg[:3]), reg[3], xs(line));  preds = lines with xs + offsets
@@ -188,5 +281,45 @@ PHNET_API int phnet_gelu_dropout_bwd(const float* dy, const float* x, float* dx,
     const DropRng rng = phnet_make_rng(rng_state, rng_call, drop_p);
     hipLaunchKernelGGL(gelu_dropout_bwd_kernel, dim3((unsigned)ceil_div64(n, NT)), dim3(NT), 0, (hipStream_t)stream, dy, x, dx, (long)n,
                        rng, rng.thresh ? 1.0f / (1.0f - drop_p) : 1.0f);
+    return phnet_launch_status();
+}
+
+// Memory tokens of one frame and stage (Router4OL.py:563-584).  feat [N][E] (E <= 1024), rows i64[L] (-1 padded),
+// tokens [L+1][E], valid u8[L+1].
+PHNET_API int phnet_memory_tokens(const float* feat, const int64_t* rows, float* tokens, uint8_t* valid,
+                                  int32_t N, int32_t E, int32_t L, void* stream)
+{
+    if (N < 1 || E < 1 || E > 1024 || L < 0 || !feat || (L && !rows) || !tokens || !valid) return PHNET_ERR_ARG;
+    const int groups = 1024 / E;
+    hipLaunchKernelGGL(memory_tokens_kernel, dim3(1), dim3(groups * E), (size_t)groups * E * sizeof(float), (hipStream_t)stream,
+                       feat, (const long long*)rows, tokens, valid, N, E, L);
+    return phnet_launch_status();
+}
+
+// gate[n] = sigmoid(relu(h[n] . w + b)); h [N][K], w [K], b [1], out [N].
+PHNET_API int phnet_gate_tail_fwd(const float* h, const float* w, const float* b, float* out, int32_t N, int32_t K, void* stream)
+{
+    if (N < 1 || K < 1 || !h || !w || !b || !out) return PHNET_ERR_ARG;
+    hipLaunchKernelGGL(gate_tail_fwd_kernel, dim3((N + NT / 64 - 1) / (NT / 64)), dim3(NT), 0, (hipStream_t)stream, h, w, b, out, N, K);
+    return phnet_launch_status();
+}
+
+// Backward of phnet_gate_tail_fwd from its output: dh [N][K] (optional), dw [K], db [1] overwritten or accumulated.  N <= 1024.
+PHNET_API int phnet_gate_tail_bwd(const float* dout, const float* out, const float* h, const float* w, float* dh, float* dw, float* db,
+                                  int32_t N, int32_t K, int32_t accumulate, void* stream)
+{
+    if (N < 1 || N > 1024 || K < 1 || !dout || !out || !h || !w || !dw || !db) return PHNET_ERR_ARG;
+    hipLaunchKernelGGL(gate_tail_bwd_kernel, dim3((K + NT - 1) / NT), dim3(NT), 0, (hipStream_t)stream, dout, out, h, w, dh, dw, db,
+                       N, K, accumulate);
+    return phnet_launch_status();
+}
+
+// priors [N][W] = (1 - gate[n]) a + gate[n] b and on_map [N][P] = priors[:, 6 + idx[p]] in one launch.
+PHNET_API int phnet_blend_priors(const float* gate, const float* a, const float* b, const int64_t* idx, float* priors, float* on_map,
+                                 int32_t N, int32_t W, int32_t P, void* stream)
+{
+    if (N < 1 || W < 7 || P < 1 || P > W || !gate || !a || !b || !idx || !priors || !on_map) return PHNET_ERR_ARG;
+    hipLaunchKernelGGL(blend_priors_kernel, dim3((N * W + NT - 1) / NT), dim3(NT), 0, (hipStream_t)stream, gate, a, b,
+                       (const long long*)idx, priors, on_map, N, W, P);
     return phnet_launch_status();
 }

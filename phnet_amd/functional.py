@@ -248,6 +248,34 @@ def lane_update(priors, head, ys, img_w, img_h):
     return _LaneUpdate.apply(priors, head, ys, img_w, img_h)
 
 
+class _GateTail(torch.autograd.Function):
+    """sigmoid(relu(h @ w.T + b)) for the 1-wide last layer of the routing gate: one launch each way instead of a padded
+    GEMM + sigmoid and their backward chain."""
+
+    @staticmethod
+    def forward(ctx, h, w, b):
+        hc, wc, bc = h.contiguous(), w.contiguous().view(-1), b.contiguous()
+        out = K.gate_tail_fwd(hc, wc, bc)
+        ctx.save_for_backward(hc, wc, out)
+        ctx.wshape = w.shape
+        ctx.w_direct, ctx.b_direct = direct_grad(w), direct_grad(b)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        h, w, out = ctx.saved_tensors
+        if ctx.w_direct is not None and ctx.b_direct is not None:
+            dh, _, _ = K.gate_tail_bwd(dout.contiguous(), out, h, w, ctx.needs_input_grad[0],
+                                       dw=ctx.w_direct.view(-1), db=ctx.b_direct, accumulate=True)
+            return dh, None, None
+        dh, dw, db = K.gate_tail_bwd(dout.contiguous(), out, h, w, ctx.needs_input_grad[0])
+        return dh, dw.view(ctx.wshape), db
+
+
+def gate_tail(h, w, b):
+    return _GateTail.apply(h, w, b)
+
+
 class DropoutStream:
     """Counter-based dropout masks (csrc/common.h): int64 device counters bumped once per training step, and a host-side id
     per dropout site of the step.  Kernels hash (counter, site, element) - no mask tensors, no RNG launches, and a

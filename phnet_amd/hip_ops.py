@@ -548,6 +548,53 @@ def attention_bwd(q, k, v, o, dout, lse, heads: int, dq, dk, dv, key_valid=None,
                                     _stream()), "phnet_attention_bwd")
 
 
+def memory_tokens(feat, rows):
+    """feat [N,E] (or [N,1,E]), rows i64[L] (-1 padded) -> (tokens [L+1,1,E], valid bool[L+1]) in one launch."""
+    _req(feat, name="feat"); _req(rows, torch.int64, "rows")
+    n, e = feat.shape[0], feat.shape[-1]
+    l = rows.numel()
+    tokens = torch.empty((l + 1, 1, e), dtype=torch.float32, device=feat.device)
+    valid = torch.empty((l + 1,), dtype=torch.bool, device=feat.device)
+    check(lib().phnet_memory_tokens(_ptr(feat), _ptr(rows), _ptr(tokens), _ptr(valid), n, e, l, _stream()), "phnet_memory_tokens")
+    return tokens, valid
+
+
+def gate_tail_fwd(h, w, b):
+    _req(h, name="h"); _req(w, name="w"); _req(b, name="b")
+    n, k = h.shape
+    if w.numel() != k or b.numel() != 1:
+        raise ValueError(f"gate_tail: h {tuple(h.shape)} vs w {tuple(w.shape)} / b {tuple(b.shape)}")
+    out = torch.empty((n,), dtype=torch.float32, device=h.device)
+    check(lib().phnet_gate_tail_fwd(_ptr(h), _ptr(w), _ptr(b), _ptr(out), n, k, _stream()), "phnet_gate_tail_fwd")
+    return out
+
+
+def gate_tail_bwd(dout, out, h, w, need_dh: bool = True, dw: Optional[torch.Tensor] = None, db: Optional[torch.Tensor] = None,
+                  accumulate: bool = False):
+    _req(dout, name="dout")
+    n, k = h.shape
+    dh = torch.empty_like(h) if need_dh else None
+    if dw is None:
+        dw = torch.empty((k,), dtype=torch.float32, device=h.device)
+        db = torch.empty((1,), dtype=torch.float32, device=h.device)
+        accumulate = False
+    check(lib().phnet_gate_tail_bwd(_ptr(dout), _ptr(out), _ptr(h), _ptr(w), _ptr(dh), _ptr(dw), _ptr(db), n, k, int(accumulate),
+                                    _stream()), "phnet_gate_tail_bwd")
+    return dh, dw, db
+
+
+def blend_priors(gate, a, b, idx):
+    """gate [N] (or [1,N,1]), a/b [1,N,W], idx i64[P] -> (priors [1,N,W], on_map [1,N,P])."""
+    _req(gate, name="gate"); _req(a, name="lines_a"); _req(b, name="lines_b"); _req(idx, torch.int64, "idx")
+    n, w = a.shape[-2], a.shape[-1]
+    p = idx.numel()
+    priors = torch.empty_like(a)
+    on_map = torch.empty(a.shape[:-1] + (p,), dtype=torch.float32, device=a.device)
+    check(lib().phnet_blend_priors(_ptr(gate), _ptr(a), _ptr(b), _ptr(idx), _ptr(priors), _ptr(on_map), n, w, p, _stream()),
+          "phnet_blend_priors")
+    return priors, on_map
+
+
 def dropout_add(x, res=None, rng=None):
     """res + dropout(x) (either part optional) in one launch; dropout_add(dy, None, rng) is the backward of the dropout."""
     _req(x, name="x")

@@ -38,5 +38,7 @@ class AdaptiveRouter4Lane(nn.Module):
         x = PF.gate_stack(xs.reshape(n, c, p), params, eps=pn.eps)        # one fused launch (csrc/gate.hip)
         mlp = self.layers[stage]
         h = PF.linear(x.reshape(n, c * p), mlp[0].weight, mlp[0].bias, relu=True)
-        h = PF.linear(h, mlp[2].weight, mlp[2].bias, relu=True)          # ReLU before the sigmoid (Router.py:45-48)
+        if mlp[2].out_features == 1:                                     # ReLU before the sigmoid (Router.py:76-80)
+            return PF.gate_tail(h, mlp[2].weight, mlp[2].bias).view(1, n, 1)
+        h = PF.linear(h, mlp[2].weight, mlp[2].bias, relu=True)
         return torch.sigmoid(h).view(1, n, -1)

@@ -207,9 +207,9 @@ class DetNetV2(nn.Module):
             pro_feat = r["local"].detach()
             out_a.append(r["pred_a"]); out_b.append(r["pred_b"]); attn_feats.append(r["attn"]); gates.append(r["gate"])
             if stage != self.refine_layers - 1:
-                w = r["gate"].detach()
-                priors = ((1 - w) * r["lines_a"] + w * r["lines_b"]).detach()
-                on_map = priors[..., 6 + self.sample_x_indexs].contiguous()
+                from phnet_amd import hip_ops as K
+                priors, on_map = K.blend_priors(r["gate"].detach().contiguous(), r["lines_a"].detach().contiguous(),
+                                                r["lines_b"].detach().contiguous(), self.sample_x_indexs)
         return {"predictions_fir": out_a, "predictions_sec": out_b}, attn_feats, gates
 
     # ---- decode ---------------------------------------------------------------------------------------------------
@@ -348,13 +348,8 @@ class RouterOL(nn.Module):
     def _tokens(self, feat, rows):
         """feat [N,1,E]; rows i64[L] positive anchors ascending, -1 padded  ->  (tokens [L+1,1,E], valid bool[L+1]):
         the positives in prior-index order, then the mean of all other anchors (Router4OL.py:563-584), fixed size."""
-        n = feat.shape[0]
-        valid = rows >= 0
-        vf = valid.to(feat.dtype)
-        safe = rows.clamp(min=0)
-        pos = feat[safe] * vf[:, None, None]
-        rest = (feat.sum(dim=0, keepdim=True) - pos.sum(dim=0, keepdim=True)) / (n - vf.sum())
-        return torch.cat([pos, rest], dim=0), torch.cat([valid, valid.new_ones(1)])
+        from phnet_amd import hip_ops as K
+        return K.memory_tokens(feat.contiguous(), rows.contiguous())
 
     def saveMemory(self, matched_indices, curr_cut):
         return [self._tokens(feat.detach(), rows) for rows, feat in zip(matched_indices, curr_cut)]

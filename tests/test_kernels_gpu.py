@@ -436,6 +436,47 @@ def test_attention_in_kernel_dropout_matches_explicit_mask(ops):
     assert not torch.equal(o1, o3) and not torch.equal(o1, o4) and torch.equal(o5, o6)
 
 
+def test_memory_tokens_gate_tail_blend(ops):
+    """The three small fused pieces of the per-frame loop against their tensor-op definitions."""
+    torch.manual_seed(21)
+    N, E = 240, 128
+    feat = torch.randn(N, 1, E, device="cuda")
+    for rows in ([3, 17, 200, -1, -1, -1, -1, -1], [-1] * 8, [0, 1, 2, 3, 4, 5, 6, 239], []):
+        r = torch.tensor(rows, dtype=torch.int64, device="cuda")
+        tok, valid = ops.memory_tokens(feat, r)
+        ok = r >= 0
+        pos = feat[r.clamp(min=0)] * ok[:, None, None].float()
+        rest = (feat.double().sum(0, keepdim=True) - pos.double().sum(0, keepdim=True)) / (N - int(ok.sum()))
+        assert valid.dtype == torch.bool and valid.tolist() == ok.tolist() + [True]
+        assert torch.equal(tok[:-1], pos)
+        close(tok[-1:], rest, 1e-5)
+    K_ = 576
+    h = torch.randn(N, K_, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn(1, K_, dtype=torch.float64) / K_ ** 0.5).requires_grad_(True)
+    b = torch.tensor([0.1], dtype=torch.float64, requires_grad=True)
+    ref = torch.sigmoid(F.relu(F.linear(h, w, b)))[:, 0]
+    g = torch.randn_like(ref)
+    ref.backward(g)
+    hd, wd, bd = dev(h.detach().float()), dev(w.detach().float().view(-1)), dev(b.detach().float())
+    out = ops.gate_tail_fwd(hd, wd, bd)
+    close(out, ref, 1e-6)
+    assert float((out == 0.5).float().mean()) > 0.2                       # closed ReLUs are part of the case
+    dh, dw, db = ops.gate_tail_bwd(dev(g.float()), out, hd, wd)
+    close(dh, h.grad, 1e-6); close(dw, w.grad.view(-1), 1e-5); close(db, b.grad, 1e-5)
+    aw, ab = torch.ones_like(wd), torch.ones_like(bd)
+    dh2, _, _ = ops.gate_tail_bwd(dev(g.float()), out, hd, wd, need_dh=False, dw=aw, db=ab, accumulate=True)
+    assert dh2 is None
+    close(aw - 1, w.grad.view(-1), 1e-5); close(ab - 1, b.grad, 1e-5)
+    W, P = 78, 36
+    gate = torch.rand(1, N, 1, device="cuda")
+    a, bl = torch.randn(1, N, W, device="cuda"), torch.randn(1, N, W, device="cuda")
+    idx = (torch.linspace(0, 1, steps=P) * 71).long().cuda()
+    pri, on_map = ops.blend_priors(gate, a, bl, idx)
+    want = (1 - gate) * a + gate * bl
+    close(pri, want, 1e-6)
+    assert torch.equal(on_map, pri[..., 6 + idx])
+
+
 @pytest.mark.parametrize("p", [0.0, 0.1, 0.5])
 def test_dropout_add_and_gelu_dropout(ops, p):
     """res + dropout(x) and dropout(gelu(x)) (transformer.py:275-298): exact at p = 0, and at p > 0 the forward and backward
