@@ -139,7 +139,7 @@ __global__ __launch_bounds__(NT) void blend_priors_kernel(const float* __restric
     }
 }
 
-// ---- lane prior update (Router4OL.py:328-345): one thread per anchor ------------------------------------------
+// ---- lane prior update (Router4OL.py:328-345): one wavefront per anchor, lanes over the S x-columns --------------------
 // head [N][HW] = (cls 2 | reg 4 | offsets S | pad); priors [N][6+S]; ys [S] = prior_ys
 // lines = (cls, start_y/start_x/theta + tanh(reg[:3]), reg[3], xs(line));  preds = lines with xs + offsets
 __global__ __launch_bounds__(NT) void lane_update_fwd_kernel(const float* __restrict__ priors, const float* __restrict__ head,
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(NT) void lane_update_fwd_kernel(const float* __rest
     // no fused multiply-adds here: theta*pi + 1e-5 sits next to tan's poles for near-horizontal anchors, where one
     // rounding more or less in the angle moves x by 1e-3; the reference rounds after the multiply and after the add
 #pragma clang fp contract(off)
-    const int i = blockIdx.x * NT + threadIdx.x;
+    const int i = blockIdx.x * (NT / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= N) return;
     const int W = 6 + S;
     const float* pr = priors + (size_t)i * W;
@@ -158,9 +158,11 @@ __global__ __launch_bounds__(NT) void lane_update_fwd_kernel(const float* __rest
     float* lo = lines + (size_t)i * W;
     const float sy = pr[2] + tanhf(hd[2]), sx = pr[3] + tanhf(hd[3]), th = pr[4] + tanhf(hd[4]);
     const float tn = tanf(th * 3.14159265358979323846f + 1e-5f);
-    po[0] = lo[0] = hd[0]; po[1] = lo[1] = hd[1];
-    po[2] = lo[2] = sy; po[3] = lo[3] = sx; po[4] = lo[4] = th; po[5] = lo[5] = hd[5];
-    for (int k = 0; k < S; ++k) {
+    if (lane == 0) {
+        po[0] = lo[0] = hd[0]; po[1] = lo[1] = hd[1];
+        po[2] = lo[2] = sy; po[3] = lo[3] = sx; po[4] = lo[4] = th; po[5] = lo[5] = hd[5];
+    }
+    for (int k = lane; k < S; k += 64) {
         const float x = (sx * (img_w - 1.0f) + ((1.0f - ys[k] - sy) * img_h / tn)) / (img_w - 1.0f);
         lo[6 + k] = x;
         po[6 + k] = x + hd[6 + k];
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(NT) void lane_update_bwd_kernel(const float* __rest
                                                              float* __restrict__ dpriors, int N, int S, int HW, float img_w, float img_h)
 {
 #pragma clang fp contract(off)
-    const int i = blockIdx.x * NT + threadIdx.x;
+    const int i = blockIdx.x * (NT / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= N) return;
     const int W = 6 + S;
     const float* dp = dpreds ? dpreds + (size_t)i * W : nullptr;
@@ -181,31 +183,32 @@ __global__ __launch_bounds__(NT) void lane_update_bwd_kernel(const float* __rest
     const float* ln = lines + (size_t)i * W;
     const float* hd = head + (size_t)i * HW;
     float* dh = dhead + (size_t)i * HW;
+    float* d = dpriors ? dpriors + (size_t)i * W : nullptr;
     auto G = [&](int c) { return (dp ? dp[c] : 0.f) + (dl ? dl[c] : 0.f); };
     const float sy = ln[2], th = ln[4];
     const float ang = th * 3.14159265358979323846f + 1e-5f;
     const float tn = tanf(ang), sn = sinf(ang);
-    float gsy = G(2), gsx = G(3), gth = G(4);
     const float kx = img_h / (img_w - 1.0f);
-    for (int k = 0; k < S; ++k) {
+    float gsy = 0.f, gsx = 0.f, gth = 0.f;
+    for (int k = lane; k < S; k += 64) {
         const float gx = G(6 + k);
         gsx += gx;
         gsy += gx * (-kx / tn);
         gth += gx * (-(1.0f - ys[k] - sy) * kx * 3.14159265358979323846f / (sn * sn));
         dh[6 + k] = dp ? dp[6 + k] : 0.f;
+        if (d) d[6 + k] = 0.f;
     }
+    for (int c = W + lane; c < HW; c += 64) dh[c] = 0.f;
+    gsy = wave_sum(gsy); gsx = wave_sum(gsx); gth = wave_sum(gth);
+    if (lane != 0) return;
+    gsy += G(2); gsx += G(3); gth += G(4);
     dh[0] = G(0); dh[1] = G(1);
     const float t2 = tanhf(hd[2]), t3 = tanhf(hd[3]), t4 = tanhf(hd[4]);
     dh[2] = gsy * (1.0f - t2 * t2);
     dh[3] = gsx * (1.0f - t3 * t3);
     dh[4] = gth * (1.0f - t4 * t4);
     dh[5] = G(5);
-    for (int c = W; c < HW; ++c) dh[c] = 0.f;
-    if (dpriors) {
-        float* d = dpriors + (size_t)i * W;
-        d[0] = d[1] = 0.f; d[2] = gsy; d[3] = gsx; d[4] = gth; d[5] = 0.f;
-        for (int k = 0; k < S; ++k) d[6 + k] = 0.f;
-    }
+    if (d) { d[0] = d[1] = 0.f; d[2] = gsy; d[3] = gsx; d[4] = gth; d[5] = 0.f; }
 }
 }  // namespace
 
@@ -217,7 +220,7 @@ PHNET_API int phnet_lane_update_fwd(const float* priors, const float* head, cons
     if (N < 0 || S < 1 || HW < 6 + S) return PHNET_ERR_ARG;
     if (N == 0) return PHNET_OK;
     if (!priors || !head || !ys || !preds || !lines) return PHNET_ERR_ARG;
-    hipLaunchKernelGGL(lane_update_fwd_kernel, dim3((N + NT - 1) / NT), dim3(NT), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(lane_update_fwd_kernel, dim3((N + NT / 64 - 1) / (NT / 64)), dim3(NT), 0, (hipStream_t)stream,
                        priors, head, ys, preds, lines, N, S, HW, img_w, img_h);
     return phnet_launch_status();
 }
@@ -230,7 +233,7 @@ PHNET_API int phnet_lane_update_bwd(const float* dpreds, const float* dlines, co
     if (N < 0 || S < 1 || HW < 6 + S) return PHNET_ERR_ARG;
     if (N == 0) return PHNET_OK;
     if (!lines || !head || !ys || !dhead || (!dpreds && !dlines)) return PHNET_ERR_ARG;
-    hipLaunchKernelGGL(lane_update_bwd_kernel, dim3((N + NT - 1) / NT), dim3(NT), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(lane_update_bwd_kernel, dim3((N + NT / 64 - 1) / (NT / 64)), dim3(NT), 0, (hipStream_t)stream,
                        dpreds, dlines, lines, head, ys, dhead, dpriors, N, S, HW, img_w, img_h);
     return phnet_launch_status();
 }

@@ -171,6 +171,7 @@ class _RoiPool(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, fmap, xs, ys):
+        ctx.set_materialize_grads(False)
         fm, xc = fmap.contiguous(), xs.contiguous()
         roi, roi_cp = K.roi_pool_fwd(fm, xc, ys, with_cp=True)
         ctx.save_for_backward(fm, xc, ys)
@@ -179,6 +180,8 @@ class _RoiPool(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, droi, _unused):
+        if droi is None:
+            return None, None, None
         fm, xs, ys = ctx.saved_tensors
         dmap = torch.zeros_like(fm) if ctx.needs_input_grad[0] else None
         dxs = K.roi_pool_bwd(droi.contiguous(), fm, xs, ys, dmap, ctx.needs_input_grad[1])
@@ -226,6 +229,7 @@ class _LaneUpdate(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, priors, head, ys, img_w, img_h):
+        ctx.set_materialize_grads(False)           # `lines` usually gets no gradient: no zero tensors for it, please
         p2 = priors.reshape(-1, priors.shape[-1]).contiguous()
         h2 = head.reshape(-1, head.shape[-1]).contiguous()
         preds, lines = K.lane_update_fwd(p2, h2, ys, img_w, img_h)
@@ -366,7 +370,7 @@ class _Attention(torch.autograd.Function):
             kv_in = kv_in.contiguous()
             q, k, v = q_in, kv_in[:, :e], kv_in[:, e:]
         rng = DropoutStream.site(q.device, dropout_p)          # attention-weight dropout drawn inside the kernels
-        kvu8 = None if key_valid is None else key_valid.to(torch.uint8).contiguous()
+        kvu8 = None if key_valid is None else key_valid.contiguous().view(torch.uint8)      # bool is one byte: no conversion launch
         out, lse = K.attention_fwd(q, k, v, heads, kvu8, rng=rng)
         ctx.save_for_backward(q_in, kv_in, out, lse, kvu8)
         ctx.heads, ctx.rng, ctx.e = heads, rng, e

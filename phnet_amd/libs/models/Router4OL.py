@@ -120,7 +120,8 @@ class DetNetV2(nn.Module):
         return (sx * (self.img_w - 1) + ((1 - self.prior_ys - sy) * self.img_h / torch.tan(theta * math.pi + 1e-5))) / (self.img_w - 1)
 
     def _expand_anchors(self, emb: torch.Tensor):
-        xs = self._line_xs(emb[:, 0:1], emb[:, 1:2], emb[:, 2:3])
+        sy, sx, theta = emb.split(1, dim=1)                              # one SplitBackward (a cat) instead of three slice backwards
+        xs = self._line_xs(sy, sx, theta)
         z = emb.new_zeros(emb.shape[0], 1)
         pri = torch.cat([z, z, emb, z, xs], dim=1)
         return pri, pri[:, 6 + self.sample_x_indexs]
@@ -324,8 +325,9 @@ class RouterOL(nn.Module):
         last_cuts = []
         total_loss = 0.0
         clip_outputs = {"lane_lines": []}
+        per_level = [f.split(1, dim=0) for f in feats]                         # SplitBackward = one cat per level, not T slice backwards
         for t in range(T):
-            cur = tuple(f[t:t + 1] for f in feats)
+            cur = tuple(lv[t] for lv in per_level)
             outputs, cur_cut, gates = self.detNet(cur, last_cuts)
             if self.training:
                 matched, frame_loss = self.criterion(outputs, lanes[t:t + 1], gates)
