@@ -199,17 +199,23 @@ __global__ __launch_bounds__(NT) void dyn_bwd_kernel(const float* __restrict__ d
     }
 }
 
-__global__ void dyn_ln_grad_reduce_kernel(const float* __restrict__ lnpart, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                          int N, int J, int accumulate)
+// dgamma/dbeta (+)= sum over anchors of lnpart [N][2][J]: 2J columns x (1024 / 2J) anchor groups, folded through LDS
+__global__ __launch_bounds__(1024) void dyn_ln_grad_reduce_kernel(const float* __restrict__ lnpart, float* __restrict__ dgamma,
+                                                                 float* __restrict__ dbeta, int N, int J, int accumulate)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 2 * J) return;
-    const int which = i / J, j = i - which * J;
-    double s = 0.0;
-#pragma unroll 8
-    for (int n = 0; n < N; ++n) s += (double)lnpart[((size_t)n * 2 + which) * J + j];
-    float* dst = (which == 0 ? dgamma : dbeta) + j;
-    *dst = accumulate ? *dst + (float)s : (float)s;
+    __shared__ float part[1024];
+    const int cols = 2 * J, groups = 1024 / cols;
+    const int c = threadIdx.x % cols, grp = threadIdx.x / cols;
+    float s = 0.f;
+    if (grp < groups)
+        for (int n = grp; n < N; n += groups) s += lnpart[(size_t)n * cols + c];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (grp != 0) return;
+    float t = 0.f;
+    for (int r = 0; r < groups; ++r) t += part[r * cols + c];
+    float* dst = (c < J ? dgamma : dbeta) + (c < J ? c : c - J);
+    *dst = accumulate ? *dst + t : t;
 }
 
 template <int K, int J>
@@ -280,7 +286,7 @@ PHNET_API int phnet_dyn_bmm_ln_relu_bwd(const float* dy, const float* x, const f
     DYN_DISPATCH(K, J, CALL)
 #undef CALL
     if (rc != PHNET_OK) return rc;
-    hipLaunchKernelGGL(dyn_ln_grad_reduce_kernel, dim3((2 * J + 255) / 256), dim3(256), 0, st, (const float*)workspace, dgamma, dbeta,
+    hipLaunchKernelGGL(dyn_ln_grad_reduce_kernel, dim3(1), dim3(1024), 0, st, (const float*)workspace, dgamma, dbeta,
                        N, J, param_accumulate);
     return phnet_launch_status();
 }

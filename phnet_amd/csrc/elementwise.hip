@@ -90,35 +90,44 @@ __global__ __launch_bounds__(NT) void gate_tail_fwd_kernel(const float* __restri
 }
 
 // dpre_n = dout_n * out_n (1 - out_n) where the ReLU was open (out_n > 0.5);  dh = dpre (x) w,  dw += sum_n dpre_n h_n,
-// db += sum_n dpre_n.  One thread per column k, all anchors in a loop (coalesced along k).
-__global__ __launch_bounds__(NT) void gate_tail_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out,
-                                                           const float* __restrict__ h, const float* __restrict__ w,
-                                                           float* __restrict__ dh, float* __restrict__ dw, float* __restrict__ db,
-                                                           int N, int K, int accumulate)
+// db += sum_n dpre_n.  A 1024-thread workgroup owns 64 columns k: 16 row groups walk the anchors (coalesced along k) and
+// their partial column sums are folded through LDS in a fixed order.
+__global__ __launch_bounds__(1024) void gate_tail_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out,
+                                                            const float* __restrict__ h, const float* __restrict__ w,
+                                                            float* __restrict__ dh, float* __restrict__ dw, float* __restrict__ db,
+                                                            int N, int K, int accumulate)
 {
     __shared__ float g[1024];
-    for (int n = threadIdx.x; n < N; n += NT) {
+    __shared__ float part[16][64];
+    for (int n = threadIdx.x; n < N; n += 1024) {
         const float o = out[n];
         g[n] = o > 0.5f ? dout[n] * o * (1.0f - o) : 0.f;
     }
     __syncthreads();
-    const int k = blockIdx.x * NT + threadIdx.x;
+    const int kc = threadIdx.x & 63, grp = threadIdx.x >> 6, k = blockIdx.x * 64 + kc;
+    float acc = 0.f;
     if (k < K) {
         const float wk = w[k];
-        float acc = 0.f;
-#pragma unroll 8
-        for (int n = 0; n < N; ++n) {
+#pragma unroll 4
+        for (int n = grp; n < N; n += 16) {
             const float gn = g[n];
             acc += gn * h[(size_t)n * K + k];
             if (dh) dh[(size_t)n * K + k] = gn * wk;
         }
-        dw[k] = accumulate ? dw[k] + acc : acc;
     }
-    if (blockIdx.x == 0 && threadIdx.x < 64) {
+    part[grp][kc] = acc;
+    __syncthreads();
+    if (grp == 0 && k < K) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += part[r][kc];
+        dw[k] = accumulate ? dw[k] + t : t;
+    }
+    if (blockIdx.x == 0 && grp == 1) {                   // one wavefront: the bias gradient
         float s = 0.f;
-        for (int n = threadIdx.x; n < N; n += 64) s += g[n];
+        for (int n = kc; n < N; n += 64) s += g[n];
         s = wave_sum(s);
-        if (threadIdx.x == 0) db[0] = accumulate ? db[0] + s : s;
+        if (kc == 0) db[0] = accumulate ? db[0] + s : s;
     }
 }
 
@@ -312,7 +321,7 @@ PHNET_API int phnet_gate_tail_bwd(const float* dout, const float* out, const flo
                                   int32_t N, int32_t K, int32_t accumulate, void* stream)
 {
     if (N < 1 || N > 1024 || K < 1 || !dout || !out || !h || !w || !dw || !db) return PHNET_ERR_ARG;
-    hipLaunchKernelGGL(gate_tail_bwd_kernel, dim3((K + NT - 1) / NT), dim3(NT), 0, (hipStream_t)stream, dout, out, h, w, dh, dw, db,
+    hipLaunchKernelGGL(gate_tail_bwd_kernel, dim3((K + 63) / 64), dim3(1024), 0, (hipStream_t)stream, dout, out, h, w, dh, dw, db,
                        N, K, accumulate);
     return phnet_launch_status();
 }

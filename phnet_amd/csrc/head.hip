@@ -155,6 +155,62 @@ __global__ __launch_bounds__(NT) void layernorm_bwd_dx_long_kernel(
     }
 }
 
+// Short rows (L <= 256: the transformer / dynamic-head LayerNorms): dx AND the slab's affine-gradient partials in one pass.
+// One wavefront per row as above; a lane owns columns lane + 64u and carries their partial sums over the wave's rows,
+// the four waves of the workgroup are folded through LDS.  partial layout as below.
+constexpr int SHORT_MAX_L = 256;
+__global__ __launch_bounds__(NT) void layernorm_bwd_short_kernel(
+    const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ w,
+    const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ dx, float* __restrict__ dres,
+    float* __restrict__ partial, long rows, int L, long rows_per_slab, int relu)
+{
+    __shared__ float red[2][NT / 64][SHORT_MAX_L];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long a = (long)blockIdx.x * rows_per_slab, e = min(rows, a + rows_per_slab);
+    float pw[SHORT_MAX_L / 64], pb[SHORT_MAX_L / 64];
+#pragma unroll
+    for (int u = 0; u < SHORT_MAX_L / 64; ++u) { pw[u] = 0.f; pb[u] = 0.f; }
+    for (long row = a + wave; row < e; row += NT / 64) {
+        const size_t o = (size_t)row * L;
+        const float mu = mean[row], rs = rstd[row];
+        float g[SHORT_MAX_L / 64], xh[SHORT_MAX_L / 64], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int u = 0; u < SHORT_MAX_L / 64; ++u) {
+            const int i = lane + 64 * u;
+            g[u] = 0.f; xh[u] = 0.f;
+            if (i < L) {
+                float gg = dy[o + i];
+                if (relu && !(y[o + i] > 0.f)) gg = 0.f;
+                g[u] = gg;
+                xh[u] = (x[o + i] - mu) * rs;
+                const float gw = gg * w[i];
+                s1 += gw;
+                s2 += gw * xh[u];
+                pw[u] += gg * xh[u];
+                pb[u] += gg;
+            }
+        }
+        s1 = wave_sum(s1) / (float)L;
+        s2 = wave_sum(s2) / (float)L;
+#pragma unroll
+        for (int u = 0; u < SHORT_MAX_L / 64; ++u) {
+            const int i = lane + 64 * u;
+            if (i < L) {
+                dx[o + i] = rs * (g[u] * w[i] - s1 - xh[u] * s2);
+                if (dres) dres[o + i] = g[u];
+            }
+        }
+    }
+    if (!partial) return;
+#pragma unroll
+    for (int u = 0; u < SHORT_MAX_L / 64; ++u) { red[0][wave][lane + 64 * u] = pw[u]; red[1][wave][lane + 64 * u] = pb[u]; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * L; i += NT) {
+        const int which = i / L, c = i - which * L;
+        partial[((size_t)blockIdx.x * 2 + which) * L + c] = (red[which][0][c] + red[which][1][c]) + (red[which][2][c] + red[which][3][c]);
+    }
+}
+
 // partial[slab][0][L] = sum_rows g*xhat, partial[slab][1][L] = sum_rows g   (rows of this slab)
 __global__ __launch_bounds__(NT) void layernorm_bwd_param_partial_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y,
@@ -297,8 +353,8 @@ PHNET_API int phnet_layernorm_fwd(const float* x, const float* w, const float* b
 
 PHNET_API uint64_t phnet_layernorm_bwd_workspace(int64_t rows, int32_t L)
 {
-    const long slabs = max((long)1, min((long)128, (long)rows / 32));
-    return (uint64_t)(slabs * 2 * L * sizeof(float));
+    (void)rows;
+    return (uint64_t)((long)128 * 2 * L * sizeof(float));        // at most 128 row slabs of (weight, bias) partials
 }
 
 // dy: gradient of the output (after the optional ReLU whose mask is y > 0).  dx overwritten; dres (optional)
@@ -312,6 +368,17 @@ PHNET_API int phnet_layernorm_bwd(const float* dy, const float* x, const float* 
     if (rows == 0) return PHNET_OK;
     if (!dy || !x || !w || !mean || !rstd || !dx || (relu && !y)) return PHNET_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
+    if (L <= SHORT_MAX_L) {                               // dx + affine partials in one launch, then the finalize
+        const bool params = dw && db;
+        const long slabs = max((long)1, min((long)128, ceil_div64(rows, 8)));
+        if (params && (!workspace || (uint64_t)(slabs * 2 * L * sizeof(float)) > ws_bytes)) return PHNET_ERR_WORKSPACE;
+        hipLaunchKernelGGL(layernorm_bwd_short_kernel, dim3((unsigned)slabs), dim3(NT), 0, st, dy, x, y, w, mean, rstd, dx, dres,
+                           params ? (float*)workspace : nullptr, (long)rows, L, ceil_div64(rows, slabs), relu);
+        if (params)
+            hipLaunchKernelGGL(layernorm_bwd_param_finalize_kernel, dim3((L + 255) / 256), dim3(256), 0, st,
+                               (const float*)workspace, dw, db, (int)slabs, L, param_accumulate);
+        return phnet_launch_status();
+    }
     if (L >= 1024 && L <= NT * LONG_MAX_PER_THREAD)
         hipLaunchKernelGGL(layernorm_bwd_dx_long_kernel, dim3((unsigned)rows), dim3(NT), 0, st,
                            dy, x, y, w, mean, rstd, dx, dres, L, relu);
