@@ -162,7 +162,7 @@ class DetNetV2(nn.Module):
         h = PF.linear(feat, w1, b1, relu=True)
         h = PF.linear(h, w2, b2, relu=True)
         out = PF.linear(h, wh, bh)
-        return PF.lane_update(priors, out.reshape(1, self.num_priors, -1), self.prior_ys, self.img_w, self.img_h)
+        return PF.lane_update(priors, out.reshape(-1, self.num_priors, out.shape[-1]), self.prior_ys, self.img_w, self.img_h)
 
     def forward_first(self, decode_feat_l, priors):
         return self._branch(decode_feat_l, priors, False)
@@ -179,23 +179,49 @@ class DetNetV2(nn.Module):
         return self._branch(feat.reshape(1, self.num_priors, -1), priors, True)
 
     # ---- one refinement stage / one frame ---------------------------------------------------------------------
-    def stage_forward(self, fmap, stage, priors, on_map, pro_feat, memory):
-        """fmap [1,h,w,C] NHWC level of this stage; priors [1,N,6+S]; on_map [1,N,P]; pro_feat [1,N,C];
-        memory None | [M,1,2C] | ([M,1,2C], valid bool[M]).  Returns dict(pred_a, lines_a, pred_b, lines_b, attn, gate, local)."""
-        roi, roi_cp = PF.roi_pool(fmap, on_map, self.prior_feat_ys)                  # [1,N,P,C], [1,N,C,P]
-        gate = self.router(roi_cp, stage)                                            # [1,N,1]
-        local = self.DHead_series[stage](pro_feat, roi)                              # [1,N,C]
+    def stage_front(self, fmap, stage, priors, on_map, pro_feat):
+        """The part of a stage that needs no other frame: ROI pooling, dynamic head, branch A.  Batched over B frames:
+        fmap [B,h,w,C]; priors [B,N,6+S]; on_map [B,N,P]; pro_feat [B,N,C].  Returns dict(roi_cp, local, pred_a, lines_a)."""
+        roi, roi_cp = PF.roi_pool(fmap, on_map, self.prior_feat_ys)                  # [B,N,P,C], [B,N,C,P]
+        local = self.DHead_series[stage](pro_feat, roi)                              # [B,N,C]
         pred_a, lines_a = self.forward_first(local, priors)
+        return dict(roi_cp=roi_cp, local=local, pred_a=pred_a, lines_a=lines_a)
+
+    def stage_back(self, front, stage, priors, memory):
+        """Gate and branch B of ONE frame on top of its stage_front results (all [1,...])."""
+        gate = self.router(front["roi_cp"], stage)                                   # [1,N,1]
+        local = front["local"]
         pos = self.PositionEmbedding.embed.weight.unsqueeze(1)                       # [N,1,C]
         attn = torch.cat([local.transpose(0, 1), pos], dim=-1)                       # [N,1,2C]
         pred_b, lines_b = self.forward_second(memory, attn, stage, priors)
-        return dict(pred_a=pred_a, lines_a=lines_a, pred_b=pred_b, lines_b=lines_b, attn=attn, gate=gate, local=local)
+        return dict(pred_a=front["pred_a"], lines_a=front["lines_a"], pred_b=pred_b, lines_b=lines_b, attn=attn, gate=gate, local=local)
 
-    def forward(self, x, last_cuts=None):
-        """x = (P3, P4, P5) NHWC [1,h,w,C] for ONE frame; last_cuts = list over remembered frames of per-stage tokens."""
+    def stage_forward(self, fmap, stage, priors, on_map, pro_feat, memory):
+        """fmap [1,h,w,C] NHWC level of this stage; priors [1,N,6+S]; on_map [1,N,P]; pro_feat [1,N,C];
+        memory None | [M,1,2C] | ([M,1,2C], valid bool[M]).  Returns dict(pred_a, lines_a, pred_b, lines_b, attn, gate, local)."""
+        return self.stage_back(self.stage_front(fmap, stage, priors, on_map, pro_feat), stage, priors, memory)
+
+    def stage0_all_frames(self, fmaps0):
+        """Stage 0 of every frame starts from the same learned anchors and embeddings, and only its branch B looks at
+        earlier frames - so ROI pooling, dynamic head and branch A of stage 0 run ONCE for the whole clip (GEMM rows
+        T*N instead of N, a fifth of the launches).  fmaps0 [T,h,w,C] = the stage-0 pyramid level of all frames.
+        Returns a list over frames of stage_front dicts ([1,...] views; their gradients meet in one cat)."""
+        T = fmaps0.shape[0]
+        if self.training:
+            self.priors, self.priors_on_featmap = self.generate_priors_from_embeddings()
+        priors = self.priors.unsqueeze(0).expand(T, -1, -1)
+        on_map = self.priors_on_featmap.unsqueeze(0).expand(T, -1, -1).contiguous()
+        pro = self.pro_embedding.weight.unsqueeze(0).expand(T, -1, -1)
+        front = self.stage_front(fmaps0, 0, priors, on_map, pro)
+        parts = {k: v.split(1, dim=0) for k, v in front.items()}
+        return [{k: parts[k][t] for k in parts} for t in range(T)]
+
+    def forward(self, x, last_cuts=None, stage0=None):
+        """x = (P3, P4, P5) NHWC [1,h,w,C] for ONE frame; last_cuts = list over remembered frames of per-stage tokens;
+        stage0 (optional) = this frame's entry of stage0_all_frames (self.priors must then be current)."""
         levels = list(x)[::-1]
         last_cuts = last_cuts or []
-        if self.training:
+        if self.training and stage0 is None:
             self.priors, self.priors_on_featmap = self.generate_priors_from_embeddings()
         priors, on_map = self.priors.unsqueeze(0), self.priors_on_featmap.unsqueeze(0)
         pro_feat = self.pro_embedding.weight.unsqueeze(0)
@@ -204,7 +230,10 @@ class DetNetV2(nn.Module):
             mem = None
             if len(last_cuts):
                 mem = (torch.cat([fr[stage][0] for fr in last_cuts], dim=0), torch.cat([fr[stage][1] for fr in last_cuts], dim=0))
-            r = self.stage_forward(levels[stage], stage, priors, on_map, pro_feat, mem)
+            if stage == 0 and stage0 is not None:
+                r = self.stage_back(stage0, 0, priors, mem)
+            else:
+                r = self.stage_forward(levels[stage], stage, priors, on_map, pro_feat, mem)
             pro_feat = r["local"].detach()
             out_a.append(r["pred_a"]); out_b.append(r["pred_b"]); attn_feats.append(r["attn"]); gates.append(r["gate"])
             if stage != self.refine_layers - 1:
@@ -280,6 +309,7 @@ class RouterOL(nn.Module):
         self.crop_size = cfg.dscfg.crop_size
         self.org_size = (cfg.dscfg.org_height, cfg.dscfg.org_width)
         self.sync_free_eval = True      # eval: fused device-side decode, one D2H copy per clip (False: per-frame get_lanes)
+        self.batch_stage0 = True        # stage-0 ROI pooling / dynamic head / branch A of all frames in one batch
 
     def _begin_clip(self):
         self.detNet._branch_cache = None                                       # weights may have changed since the last clip
@@ -292,9 +322,10 @@ class RouterOL(nn.Module):
         self._begin_clip()
         feats = self.backbone(frame)
         last_cuts, rows, nums, anchors = [], [], [], []
+        stage0 = self.detNet.stage0_all_frames(feats[-1]) if self.batch_stage0 else None
         for t in range(frame.shape[0]):
             cur = tuple(f[t:t + 1] for f in feats)
-            outputs, cur_cut, gates = self.detNet(cur, last_cuts)
+            outputs, cur_cut, gates = self.detNet(cur, last_cuts, None if stage0 is None else stage0[t])
             d = torch.stack(gates, dim=0).mean(dim=0)
             lines = outputs["predictions_sec"][-1] * d + outputs["predictions_fir"][-1] * (1 - d)
             dec = self.detNet.decode_device(lines[0])
@@ -326,9 +357,10 @@ class RouterOL(nn.Module):
         total_loss = 0.0
         clip_outputs = {"lane_lines": []}
         per_level = [f.split(1, dim=0) for f in feats]                         # SplitBackward = one cat per level, not T slice backwards
+        stage0 = self.detNet.stage0_all_frames(feats[-1]) if self.batch_stage0 else None
         for t in range(T):
             cur = tuple(lv[t] for lv in per_level)
-            outputs, cur_cut, gates = self.detNet(cur, last_cuts)
+            outputs, cur_cut, gates = self.detNet(cur, last_cuts, None if stage0 is None else stage0[t])
             if self.training:
                 matched, frame_loss = self.criterion(outputs, lanes[t:t + 1], gates)
                 total_loss = total_loss + frame_loss

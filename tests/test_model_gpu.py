@@ -82,8 +82,8 @@ def _record_heads(model):
     det, crit = model.detNet, model.criterion
     det_fwd, crit_fwd = det.forward, crit.forward
 
-    def det_hook(x, last_cuts=None):
-        o, cut, diff = det_fwd(x, last_cuts)
+    def det_hook(x, last_cuts=None, stage0=None):
+        o, cut, diff = det_fwd(x, last_cuts, stage0)
         rec["fir"].append(torch.stack([p.detach()[0] for p in o["predictions_fir"]]).cpu())
         rec["sec"].append(torch.stack([p.detach()[0] for p in o["predictions_sec"]]).cpu())
         rec["gate"].append(torch.stack([d.detach()[0, :, 0] for d in diff]).cpu())
@@ -338,6 +338,33 @@ def test_dropout_masks_advance_with_each_graph_replay_and_match_between_forward_
     # with another mask draw the output moves: the masks are really on
     with torch.no_grad():
         assert float(loss_with_pinned_masks(snap + 8)) != float(loss_with_pinned_masks(snap))
+
+
+def test_stage0_batched_over_frames_equals_per_frame_stage0():
+    """RouterOL.batch_stage0: ROI pooling / dynamic head / branch A of stage 0 for all frames in one batch is the same
+    computation as doing them frame by frame (rows are independent): loss and gradients agree to fp32 re-association."""
+    g = O.Geometry(img_h=64, img_w=160, arch="resnet18")
+    T = 4
+    frames, lanes = synth.make_clip(g, T, seed=9).cuda(), synth.make_targets(g, T).cuda()
+    out = []
+    for batched in (False, True):
+        model = _build(g).train()
+        model.batch_stage0 = batched
+        loss = model({"frame": frames, "lanes": lanes})
+        loss.backward()
+        out.append((float(loss), {k: p.grad.double().norm().item() for k, p in model.named_parameters() if p.grad is not None}))
+    (la, ga), (lb, gb) = out
+    assert abs(la - lb) <= 1e-5 * abs(la), (la, lb)
+    assert ga.keys() == gb.keys()
+    for k in ga:
+        assert abs(ga[k] - gb[k]) <= 2e-3 * ga[k] + 1e-5, (k, ga[k], gb[k])      # 1e-5: biases in front of a LayerNorm have pure-noise gradients
+    model.eval()
+    with torch.no_grad():
+        a = model.infer_device(frames)
+        model.batch_stage0 = False
+        b = model.infer_device(frames)
+    assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    _close(a[0], b[0], 1e-4, "kept rows")
 
 
 def test_arena_direct_accumulation_equals_autograd_accumulation():
