@@ -108,12 +108,11 @@ def main():
             if d_.dim() == 4 and not d_.is_contiguous():
                 d_ = d_.permute(0, 2, 3, 1)          # channels_last parameter: broadcast its dense OHWI view
             dist.broadcast(d_, src=0)
-    arena = GradArena(model.parameters())          # flat fp32 gradient buffer; HIP backward kernels accumulate into it
-    decay = [p for p in model.parameters() if p.dim() > 1]
-    no_decay = [p for p in model.parameters() if p.dim() <= 1]
+    # flat fp32 arenas: the HIP backward kernels accumulate straight into the gradient arena, one launch of the flat AdamW
+    # updates every parameter (torch.optim.AdamW semantics and the reference's grouping: no decay on 1-D parameters)
+    from phnet_amd.optim import FlatAdamW
     use_graph = not args.eager
-    opt = torch.optim.AdamW([{"params": decay, "weight_decay": 5e-4}, {"params": no_decay, "weight_decay": 0.0}],
-                            lr=5e-4, betas=(0.9, 0.999), fused=True, capturable=use_graph)
+    opt, arena = FlatAdamW.for_model(model, lr=5e-4, betas=(0.9, 0.999), weight_decay=5e-4)
     T = args.frames
     lanes = make_targets(args.height, args.width, T).to(dev)
     clips = [make_clip(args.height, args.width, T, seed=3407 + rank + 17 * i).to(dev) for i in range(4)]

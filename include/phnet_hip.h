@@ -73,12 +73,13 @@ int phnet_conv2d_dgrad(const float* dy, const float* w, const float* addend, flo
                        int32_t N, int32_t Hi, int32_t Wi, int32_t Ci, int32_t Co, int32_t R, int32_t S,
                        int32_t stride, int32_t pad, void* workspace, uint64_t ws_bytes, void* stream);
 /* host-side query (no device work; bm/bn/splits/k_tile are HOST pointers): tile, split-K factor and K-tile depth the
- * two calls above use, i.e. the template arguments of the conv_igemm_kernel<BM, BN, DGRAD, BKT> they launch. */
+ * two calls above use, i.e. the template arguments of the conv_igemm_kernel<BM, BN, DGRAD, BKT, UNI> they launch
+ * (UNI = uniform-tap variant: 64x64 tile and A-side channel count % BKT == 0). */
 int phnet_conv2d_plan(int64_t M, int32_t Co, int32_t K, uint64_t ws_bytes, int32_t* bm, int32_t* bn, int32_t* splits,
                       int32_t* k_tile);
 /* tuning aid for benchmarks only (process-global): force tile/split-K of the next fwd/dgrad calls; bm=0 -> heuristic. */
 int phnet_tune_force_conv_tile(int32_t bm, int32_t bn, int32_t splits);
-int phnet_tune_force_k_tile(int32_t k_tile);   /* 0 = heuristic, else 16 | 32 | 64 */
+int phnet_tune_force_k_tile(int32_t k_tile);   /* 0 = heuristic, else 16 | 32 | 64; -1 / -2: uniform-tap kernel variant off / on */
 int phnet_tune_wgrad(int32_t allow_bm128, int32_t target_blocks);   /* wgrad tile / split-K policy */
 uint64_t phnet_conv2d_wgrad_workspace(int32_t N, int32_t Hi, int32_t Wi, int32_t Ci, int32_t Co,
                                       int32_t R, int32_t S, int32_t stride, int32_t pad);
@@ -221,6 +222,12 @@ int phnet_gate_tail_bwd(const float* dout, const float* out, const float* h, con
                         int32_t N, int32_t K, int32_t accumulate, void* stream);
 int phnet_blend_priors(const float* gate, const float* a, const float* b, const int64_t* idx, float* priors, float* on_map,
                        int32_t N, int32_t W, int32_t P, void* stream);
+
+/* ---- optimizer: one AdamW step (torch.optim.AdamW semantics, libs/utils/optimizer.py:33-35) over flat parameter / gradient /
+ * moment arrays; elements [0, n_decay) get decoupled weight decay.  n % 4 == 0.  step: device int64, 1-based, already
+ * incremented by the caller for this step. ---- */
+int phnet_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, int64_t n_decay, const int64_t* step,
+                     float lr, float beta1, float beta2, float eps, float weight_decay, void* stream);
 
 /* ---- per-anchor dynamic convolution: y[n] = relu(LayerNorm_J(x[n] @ w[n]) * gamma + beta), replacing torch.bmm + norm1/norm2
  * + ReLU in libs/models/utils/dynamic_head.py:40-51 (and their backward).  x [N][P][K], w [N][K][J] (generated per anchor),

@@ -13,24 +13,38 @@ import torch
 _DIRECT: Dict[int, "GradArena"] = {}
 
 
+def _view_like(chunk: torch.Tensor, p: torch.Tensor) -> torch.Tensor:
+    """A view of the flat `chunk` with the shape AND strides of parameter `p` (dense, or channels_last 4-D)."""
+    if p.dim() == 4 and not p.is_contiguous() and p.is_contiguous(memory_format=torch.channels_last):
+        co, ci, r, s = p.shape
+        return chunk.view(co, r, s, ci).permute(0, 3, 1, 2)
+    return chunk.view(p.shape)
+
+
 class GradArena:
-    def __init__(self, params: Iterable[torch.nn.Parameter]):
+    def __init__(self, params: Iterable[torch.nn.Parameter], flatten_params: bool = False):
+        """flatten_params=True also moves the parameter VALUES into one flat buffer (`flat_params`, same element order as
+        the gradients) so that an optimizer can update everything with one launch (phnet_amd.optim.FlatAdamW)."""
         self.params = [p for p in params if p.requires_grad]
         dev = self.params[0].device
         total = sum(p.numel() for p in self.params)
-        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        pad = (-total) % 4                                            # the flat optimizer kernel works on float4
+        self.flat = torch.zeros(total + pad, dtype=torch.float32, device=dev)
+        self.flat_params = torch.zeros(total + pad, dtype=torch.float32, device=dev) if flatten_params else None
+        self.offsets = {}
         off = 0
         for p in self.params:
             n = p.numel()
-            chunk = self.flat[off:off + n]
-            if p.dim() == 4 and not p.is_contiguous() and p.is_contiguous(memory_format=torch.channels_last):
-                co, ci, r, s = p.shape
-                g = chunk.view(co, r, s, ci).permute(0, 3, 1, 2)          # same strides as the channels_last parameter
-            else:
-                g = chunk.view(p.shape)
-            p.grad = g
+            p.grad = _view_like(self.flat[off:off + n], p)
+            if flatten_params:
+                with torch.no_grad():
+                    dst = _view_like(self.flat_params[off:off + n], p)
+                    dst.copy_(p.data)
+                    p.data = dst
+            self.offsets[id(p)] = (off, n)
             _DIRECT[id(p)] = self
             off += n
+        self.numel = total
 
     def zero(self):
         self.flat.zero_()

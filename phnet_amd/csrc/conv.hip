@@ -34,7 +34,7 @@ struct ConvShape {
 
 struct RowCoord { int base, iy0, ix0; bool ok; };
 
-template <int BM, int BN, bool B_DGRAD, int BKT>
+template <int BM, int BN, bool B_DGRAD, int BKT, bool UNI>
 __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(
     const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ bias,
     const float* __restrict__ addend, float* __restrict__ out, ConvShape g, int relu)
@@ -108,35 +108,54 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(
         }
     }
 
-    f32x4 a_reg[A_LOADS], b_reg[B_LOADS];
+    // Uniform-tap fast path: when the A-side channel count is a multiple of the K tile, every K tile lies inside ONE filter
+    // tap (r,q), the same for the whole workgroup, so the tap walks in scalar registers and a thread's address math per
+    // tile is a handful of VALU ops (the general path below carries a per-thread (c,r,q) decomposition and made the
+    // trunk loops VALU-bound: ~190 instructions per 8 MFMAs).
+    constexpr bool uni = UNI;                            // host guarantees g.Ci % BKT == 0
+    int ur = 0, uq = 0, uc0 = 0;
+    if (uni) {
+        const int rs = k_begin / g.Ci;
+        uc0 = k_begin - rs * g.Ci;
+        ur = rs / g.S;
+        uq = rs - ur * g.S;
+    }
+
+    // The loads are BRANCH-FREE: an out-of-range element reads element 0 of its array and is zeroed when it is written to
+    // LDS (validity bits travel in `mask`: A loads in bits 0.., B loads in bits 16..), so the loop body is straight-line
+    // code the compiler can schedule and count (s_waitcnt) exactly.  (A second register set prefetching two tiles ahead
+    // was measured too: +4 % on the trunk forward, -3 % on the skinny head GEMMs, no gain on the step - not kept.)
+    f32x4 a_set0[A_LOADS], b_set0[B_LOADS];
+    unsigned mask0 = 0;
     // loads the K tile that starts at kt; MUST be called with kt = k_begin, k_begin+BKT, ... in order
-    auto load_global = [&](int kt) {
+    auto load_global = [&](int kt, f32x4 (&a_reg)[A_LOADS], f32x4 (&b_reg)[B_LOADS], unsigned& mask) {
+        mask = 0;
         // A: CHUNKS consecutive lanes fetch BKT*4 contiguous bytes of one pixel tap
         const int k0 = kt + a_chunk * 4;
         const bool kok = k0 < k_end;
+        const int tap_r = uni ? ur : ka.r, tap_q = uni ? uq : ka.q, tap_c = uni ? uc0 + a_chunk * 4 : ka.c;
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i) {
-            int ty = rc[i].iy0 + ka.r, tx = rc[i].ix0 + ka.q;
+            int ty = rc[i].iy0 + tap_r, tx = rc[i].ix0 + tap_q;
             bool ok = kok && rc[i].ok && ty >= 0 && tx >= 0;
-            if (g.in_dil == 2) {
+            if (g.in_dil == 2) {                        // dgrad of a stride-2 conv (strides > 2 are rejected on the host)
                 ok = ok && !((ty | tx) & 1);
                 ty >>= 1; tx >>= 1;
-            } else if (g.in_dil > 2) {
-                ok = ok && (ty % g.in_dil == 0) && (tx % g.in_dil == 0);
-                ty /= g.in_dil; tx /= g.in_dil;
             }
             ok = ok && ty < g.Hi && tx < g.Wi;
-            a_reg[i] = ok ? *reinterpret_cast<const f32x4*>(X + ((size_t)(rc[i].base + ty * g.Wi + tx)) * g.Ci + ka.c)
-                          : f32x4{0.f, 0.f, 0.f, 0.f};
+            const int pix = ok ? rc[i].base + ty * g.Wi + tx : 0;         // masked: pixel 0 (valid memory, value discarded)
+            a_reg[i] = *reinterpret_cast<const f32x4*>(X + (size_t)pix * g.Ci + (kok ? tap_c : 0));
+            mask |= (unsigned)ok << i;
         }
-        kpos_advance(ka, g.Ci);
+        if (!uni) kpos_advance(ka, g.Ci);
         if (!B_DGRAD) {
             // B rows = output channels, K contiguous in the OHWI weight
 #pragma unroll
             for (int i = 0; i < B_LOADS; ++i) {
                 const int n = n0 + a_row + ROWS_PER_PASS * i;
-                b_reg[i] = (kok && n < g.Co) ? *reinterpret_cast<const f32x4*>(W + (size_t)n * K + k0)
-                                             : f32x4{0.f, 0.f, 0.f, 0.f};
+                const bool ok = kok && n < g.Co;
+                b_reg[i] = *reinterpret_cast<const f32x4*>(W + (size_t)(ok ? n : 0) * K + (kok ? k0 : 0));
+                mask |= (unsigned)ok << (16 + i);
             }
         } else {
             // B rows = k = (r,q,co) of the dgrad sum; columns = ci, contiguous in W[co][R-1-r][S-1-q][:]
@@ -145,27 +164,37 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(
             for (int i = 0; i < B_LOADS; ++i) {
                 const int k = kt + b_kk[i], n = n0 + b_ch[i] * 4;
                 const bool ok = k < k_end && n < g.Co;
-                b_reg[i] = ok ? *reinterpret_cast<const f32x4*>(
-                                    W + ((size_t)(kb[i].c * g.R + (g.R - 1 - kb[i].r)) * g.S + (g.S - 1 - kb[i].q)) * g.Co + n)
-                              : f32x4{0.f, 0.f, 0.f, 0.f};
-                kpos_advance(kb[i], g.Ci);
+                const int wc = uni ? uc0 + b_kk[i] : kb[i].c, wr = uni ? ur : kb[i].r, wq = uni ? uq : kb[i].q;
+                const int wrow = ok ? (wc * g.R + (g.R - 1 - wr)) * g.S + (g.S - 1 - wq) : 0;
+                b_reg[i] = *reinterpret_cast<const f32x4*>(W + (size_t)wrow * g.Co + (ok ? n : 0));
+                mask |= (unsigned)ok << (16 + i);
+                if (!uni) kpos_advance(kb[i], g.Ci);
+            }
+        }
+        if (uni) {                                       // scalar tap walk
+            uc0 += BKT;
+            if (uc0 >= g.Ci) {
+                uc0 = 0;
+                if (++uq == g.S) { uq = 0; ++ur; }
             }
         }
     };
-    auto store_lds = [&](int buf) {
+    auto store_lds = [&](int buf, const f32x4 (&a_reg)[A_LOADS], const f32x4 (&b_reg)[B_LOADS], unsigned mask) {
         float* a = As + buf * A_FLOATS;
         float* b = Bs + buf * B_FLOATS;
+        const f32x4 zero{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i)
-            *reinterpret_cast<f32x4*>(a + (a_row + ROWS_PER_PASS * i) * A_PITCH + a_chunk * 4) = a_reg[i];
+            *reinterpret_cast<f32x4*>(a + (a_row + ROWS_PER_PASS * i) * A_PITCH + a_chunk * 4) = (mask >> i) & 1u ? a_reg[i] : zero;
         if (!B_DGRAD) {
 #pragma unroll
             for (int i = 0; i < B_LOADS; ++i)
-                *reinterpret_cast<f32x4*>(b + (a_row + ROWS_PER_PASS * i) * B_PITCH + a_chunk * 4) = b_reg[i];
+                *reinterpret_cast<f32x4*>(b + (a_row + ROWS_PER_PASS * i) * B_PITCH + a_chunk * 4) =
+                    (mask >> (16 + i)) & 1u ? b_reg[i] : zero;
         } else {
 #pragma unroll
             for (int i = 0; i < B_LOADS; ++i)
-                *reinterpret_cast<f32x4*>(b + b_kk[i] * B_PITCH + b_ch[i] * 4) = b_reg[i];
+                *reinterpret_cast<f32x4*>(b + b_kk[i] * B_PITCH + b_ch[i] * 4) = (mask >> (16 + i)) & 1u ? b_reg[i] : zero;
         }
     };
 
@@ -177,24 +206,28 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+    auto multiply_tile = [&](int buf, int kt) {
+#pragma unroll
+        for (int ks = 0; ks < BKT / BK; ++ks) {
+            if (BKT > BK && kt + ks * BK >= k_end) break;              // ragged K tail of a deep tile
+            float a[FM][8], b[FN][8];
+            read_kcontig<FM, A_PITCH>(As + buf * A_FLOATS + wm * A_PITCH, lane, ks, a);
+            if (!B_DGRAD) read_kcontig<FN, B_PITCH>(Bs + buf * B_FLOATS + wn * B_PITCH, lane, ks, b);
+            else read_kstrided<FN, B_PITCH>(Bs + buf * B_FLOATS + wn, lane, ks, b);
+            mma_step<FM, FN>(a, b, acc);
+        }
+    };
+
     if (k_begin < k_end) {
-        load_global(k_begin);
-        store_lds(0);
+        const int ntiles = (k_end - k_begin + BKT - 1) / BKT;
+        load_global(k_begin, a_set0, b_set0, mask0);
+        store_lds(0, a_set0, b_set0, mask0);
         __syncthreads();
         int buf = 0;
-        for (int kt = k_begin; kt < k_end; kt += BKT) {
-            const bool more = kt + BKT < k_end;
-            if (more) load_global(kt + BKT);
-#pragma unroll
-            for (int ks = 0; ks < BKT / BK; ++ks) {
-                if (BKT > BK && kt + ks * BK >= k_end) break;          // ragged K tail of a deep tile
-                float a[FM][8], b[FN][8];
-                read_kcontig<FM, A_PITCH>(As + buf * A_FLOATS + wm * A_PITCH, lane, ks, a);
-                if (!B_DGRAD) read_kcontig<FN, B_PITCH>(Bs + buf * B_FLOATS + wn * B_PITCH, lane, ks, b);
-                else read_kstrided<FN, B_PITCH>(Bs + buf * B_FLOATS + wn, lane, ks, b);
-                mma_step<FM, FN>(a, b, acc);
-            }
-            if (more) store_lds(buf ^ 1);
+        for (int t = 0; t < ntiles; ++t) {
+            load_global(k_begin + (t + 1) * BKT, a_set0, b_set0, mask0);      // past the end: fully masked
+            multiply_tile(buf, k_begin + t * BKT);
+            store_lds(buf ^ 1, a_set0, b_set0, mask0);
             __syncthreads();
             buf ^= 1;
         }
@@ -455,6 +488,7 @@ int k_tile_for(long M, int K) { return (M <= 2048 && K >= 64) ? 64 : BK; }
 
 int g_force_bm = 0, g_force_bn = 0, g_force_splits = 0;      // tuning aid (phnet_tune_force_conv_tile)
 int g_force_kt = 0;                                          // tuning aid (phnet_tune_force_k_tile)
+int g_uniform_tap = 1;                                       // tuning aid (phnet_tune_force_k_tile(-1) switches the uniform-tap variant off)
 int g_wgrad_bm128 = 1, g_wgrad_target = 768;                // tuning aids (phnet_tune_wgrad)
 
 ConvPlan plan_conv(long M, int Co, int K, bool has_ws, size_t ws_bytes)
@@ -495,29 +529,32 @@ int launch_conv(const float* X, const float* W, const float* bias, const float* 
     const int bkt = g_force_kt ? g_force_kt : k_tile_for(M, K);
     const int ksteps = (K + bkt - 1) / bkt;
     g.k_per_split = ((ksteps + splits - 1) / splits) * bkt;
-#define PHNET_LAUNCH_CONV_(BM_, BN_, BKT_)                                                                              \
+#define PHNET_LAUNCH_CONV_(BM_, BN_, BKT_, UNI_)                                                                        \
     do {                                                                                                                \
         constexpr size_t lds_ = 2 * (KContigTile<BM_, BKT_>::FLOATS +                                                   \
                                      (DGRAD ? KStridedTile<BN_, BKT_>::FLOATS : KContigTile<BN_, BKT_>::FLOATS)) * 4;   \
         static bool attr_set_ = false;                                                                                  \
         if (lds_ > 64 * 1024 && !attr_set_) {                                                                           \
-            (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BM_, BN_, DGRAD, BKT_>,                            \
+            (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BM_, BN_, DGRAD, BKT_, UNI_>,                      \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_);                                 \
             attr_set_ = true;                                                                                           \
         }                                                                                                               \
-        hipLaunchKernelGGL((conv_igemm_kernel<BM_, BN_, DGRAD, BKT_>), grid, dim3(THREADS), lds_, st, X, W, bias,       \
+        hipLaunchKernelGGL((conv_igemm_kernel<BM_, BN_, DGRAD, BKT_, UNI_>), grid, dim3(THREADS), lds_, st, X, W, bias, \
                            addend, dst, g, relu);                                                                       \
     } while (0)
-#define PHNET_LAUNCH_CONV(BM_, BN_)                                                                                     \
+#define PHNET_LAUNCH_CONV(BM_, BN_, UNI_)                                                                               \
     do {                                                                                                                \
-        if (bkt == 64) PHNET_LAUNCH_CONV_(BM_, BN_, 64);                                                                \
-        else if (bkt == 32) PHNET_LAUNCH_CONV_(BM_, BN_, 32);                                                           \
-        else PHNET_LAUNCH_CONV_(BM_, BN_, 16);                                                                          \
+        if (bkt == 64) PHNET_LAUNCH_CONV_(BM_, BN_, 64, UNI_);                                                          \
+        else if (bkt == 32) PHNET_LAUNCH_CONV_(BM_, BN_, 32, UNI_);                                                     \
+        else PHNET_LAUNCH_CONV_(BM_, BN_, 16, UNI_);                                                                    \
     } while (0)
-    if (t.bm == 128 && t.bn == 128) PHNET_LAUNCH_CONV(128, 128);
-    else if (t.bm == 128 && t.bn == 64) PHNET_LAUNCH_CONV(128, 64);
-    else if (t.bm == 64 && t.bn == 128) PHNET_LAUNCH_CONV(64, 128);
-    else PHNET_LAUNCH_CONV(64, 64);
+    // uniform-tap variant (the production tile only): the A-side channel count is a multiple of the K tile
+    const bool uni = (g.Ci % bkt) == 0 && g_uniform_tap;
+    if (t.bm == 128 && t.bn == 128) PHNET_LAUNCH_CONV(128, 128, false);
+    else if (t.bm == 128 && t.bn == 64) PHNET_LAUNCH_CONV(128, 64, false);
+    else if (t.bm == 64 && t.bn == 128) PHNET_LAUNCH_CONV(64, 128, false);
+    else if (uni) PHNET_LAUNCH_CONV(64, 64, true);
+    else PHNET_LAUNCH_CONV(64, 64, false);
 #undef PHNET_LAUNCH_CONV_
 #undef PHNET_LAUNCH_CONV
     if (splits > 1) {
@@ -560,6 +597,7 @@ PHNET_API int phnet_tune_wgrad(int32_t allow_bm128, int32_t target_blocks)
 
 PHNET_API int phnet_tune_force_k_tile(int32_t kt)
 {
+    if (kt == -1 || kt == -2) { g_uniform_tap = kt == -2; return PHNET_OK; }     // -1: uniform-tap variant off, -2: on again
     if (kt != 0 && kt != 16 && kt != 32 && kt != 64) return PHNET_ERR_ARG;
     g_force_kt = kt;
     return PHNET_OK;
@@ -593,6 +631,7 @@ PHNET_API int phnet_conv2d_dgrad(const float* dy, const float* w, const float* a
 {
     if (N < 0 || Hi < 1 || Wi < 1 || Ci < 4 || Co < 4 || (Ci & 3) || (Co & 3) || R < 1 || S < 1 || stride < 1 || pad < 0)
         return PHNET_ERR_ARG;
+    if (stride > 2) return PHNET_ERR_ARG;          // the data gradient supports strides 1 and 2 (all the model has)
     if (N == 0) return PHNET_OK;
     if (!dy || !w || !dx) return PHNET_ERR_ARG;
     ConvShape g{};

@@ -3,6 +3,7 @@
 
 namespace {
 constexpr int NT = 256;
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(NT) void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                       float* __restrict__ dx, long n)
@@ -44,6 +45,32 @@ __global__ __launch_bounds__(NT) void gelu_dropout_bwd_kernel(const float* __res
     if (i >= n) return;
     const bool kept = !rng.thresh || phnet_rng_keep(phnet_rng_seed(rng), (uint64_t)i, rng.thresh);
     dx[i] = kept ? dy[i] * scale * gelu_erf_grad(x[i]) : 0.f;
+}
+
+// ---- AdamW over the flat parameter / gradient arenas (libs/utils/optimizer.py:33-35: optim.AdamW) -------------------------------
+// decoupled weight decay on elements [0, n_decay); same update order as torch's single-tensor AdamW:
+//   p *= 1 - lr*wd;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= (lr / (1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+__global__ __launch_bounds__(NT) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long n4, long n_decay, const long long* __restrict__ step,
+                                                   float lr, float b1, float b2, float eps, float wd)
+{
+    const long i = (long)blockIdx.x * NT + threadIdx.x;
+    if (i >= n4) return;
+    const float t = (float)step[0];
+    const float c1 = 1.0f - powf(b1, t), c2s = sqrtf(1.0f - powf(b2, t));
+    const float step_size = lr / c1;
+    f32x4v pp = reinterpret_cast<f32x4v*>(p)[i], mm = reinterpret_cast<f32x4v*>(m)[i], vv = reinterpret_cast<f32x4v*>(v)[i];
+    const f32x4v gg = reinterpret_cast<const f32x4v*>(g)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float pe = pp[e];
+        if (i * 4 + e < n_decay) pe *= 1.0f - lr * wd;
+        const float me = b1 * mm[e] + (1.0f - b1) * gg[e];
+        const float ve = b2 * vv[e] + (1.0f - b2) * gg[e] * gg[e];
+        pe -= step_size * (me / (sqrtf(ve) / c2s + eps));
+        pp[e] = pe; mm[e] = me; vv[e] = ve;
+    }
+    reinterpret_cast<f32x4v*>(p)[i] = pp; reinterpret_cast<f32x4v*>(m)[i] = mm; reinterpret_cast<f32x4v*>(v)[i] = vv;
 }
 
 // ---- cross-frame memory tokens (Router4OL.py:563-584): the positives' features in prior-index order, then the mean of
@@ -333,5 +360,19 @@ PHNET_API int phnet_blend_priors(const float* gate, const float* a, const float*
     if (N < 1 || W < 7 || P < 1 || P > W || !gate || !a || !b || !idx || !priors || !on_map) return PHNET_ERR_ARG;
     hipLaunchKernelGGL(blend_priors_kernel, dim3((N * W + NT - 1) / NT), dim3(NT), 0, (hipStream_t)stream, gate, a, b,
                        (const long long*)idx, priors, on_map, N, W, P);
+    return phnet_launch_status();
+}
+
+// One AdamW step over flat fp32 arrays (n % 4 == 0, 16-byte aligned); elements [0, n_decay) get decoupled weight decay.
+// step: DEVICE pointer to the 1-based step count as int64 (the caller increments it before the call - part of the captured
+// step, so replays advance the bias correction).
+PHNET_API int phnet_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, int64_t n_decay, const int64_t* step,
+                               float lr, float beta1, float beta2, float eps, float weight_decay, void* stream)
+{
+    if (n < 0 || (n & 3) || n_decay < 0 || n_decay > n) return PHNET_ERR_ARG;
+    if (n == 0) return PHNET_OK;
+    if (!p || !g || !m || !v || !step) return PHNET_ERR_ARG;
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)ceil_div64(n / 4, NT)), dim3(NT), 0, (hipStream_t)stream, p, g, m, v, (long)(n / 4),
+                       (long)n_decay, (const long long*)step, lr, beta1, beta2, eps, weight_decay);
     return phnet_launch_status();
 }

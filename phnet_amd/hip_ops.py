@@ -16,12 +16,14 @@ _WS = {}
 TIMER = None
 
 
-def _gemm_symbol(m, co, k, ws_bytes, dgrad):
+def _gemm_symbol(m, co, k, ws_bytes, dgrad, ci_a):
     import ctypes
     bm, bn, sp, kt = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
     check(lib().phnet_conv2d_plan(m, co, k, ws_bytes, ctypes.byref(bm), ctypes.byref(bn), ctypes.byref(sp), ctypes.byref(kt)),
           "phnet_conv2d_plan")
-    return f"conv_igemm_kernel<{bm.value}, {bn.value}, {'true' if dgrad else 'false'}, {kt.value}>", sp.value
+    uni = bm.value == 64 and bn.value == 64 and ci_a % kt.value == 0      # uniform-tap variant (csrc/conv.hip)
+    return (f"conv_igemm_kernel<{bm.value}, {bn.value}, {'true' if dgrad else 'false'}, {kt.value}, {'true' if uni else 'false'}>",
+            sp.value)
 
 
 def _timed_launch(sym_fn, flops, launch):
@@ -128,7 +130,7 @@ def conv2d_fwd(x, w, bias, stride: int, pad: int, relu: bool = False, out: Optio
         out = torch.empty((n, ho, wo, co), dtype=torch.float32, device=x.device)
     ws = workspace(8 * n * ho * wo * co * 4 if n * ho * wo * co < (1 << 23) else 0, x.device)
     m, k = n * ho * wo, r * s * ci
-    _timed_launch(lambda: _gemm_symbol(m, co, k, ws.numel(), False), 2.0 * m * co * k,
+    _timed_launch(lambda: _gemm_symbol(m, co, k, ws.numel(), False, ci), 2.0 * m * co * k,
                   lambda: check(lib().phnet_conv2d_fwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(out), n, hi, wi, ci, co, r, s, stride,
                                                        pad, int(relu), _ptr(ws), ws.numel(), _stream()), "phnet_conv2d_fwd"))
     return out
@@ -142,7 +144,7 @@ def conv2d_dgrad(dy, w, in_hw: Tuple[int, int], stride: int, pad: int, addend: O
     dx = torch.empty((n, hi, wi, ci), dtype=torch.float32, device=dy.device)
     ws = workspace(8 * n * hi * wi * ci * 4 if n * hi * wi * ci < (1 << 23) else 0, dy.device)
     m, k = n * hi * wi, r * s * co
-    _timed_launch(lambda: _gemm_symbol(m, ci, k, ws.numel(), True), 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * co * r * s * ci,
+    _timed_launch(lambda: _gemm_symbol(m, ci, k, ws.numel(), True, co), 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * co * r * s * ci,
                   lambda: check(lib().phnet_conv2d_dgrad(_ptr(dy), _ptr(w), _ptr(addend), _ptr(dx), n, hi, wi, ci, co, r, s, stride,
                                                          pad, _ptr(ws), ws.numel(), _stream()), "phnet_conv2d_dgrad"))
     return dx
@@ -593,6 +595,17 @@ def blend_priors(gate, a, b, idx):
     check(lib().phnet_blend_priors(_ptr(gate), _ptr(a), _ptr(b), _ptr(idx), _ptr(priors), _ptr(on_map), n, w, p, _stream()),
           "phnet_blend_priors")
     return priors, on_map
+
+
+def adamw_step(p, g, m, v, n_decay: int, step, lr: float, beta1: float, beta2: float, eps: float, weight_decay: float):
+    """In-place AdamW over flat fp32 buffers (all the same length, a multiple of 4); step = int64[1] device tensor."""
+    for t, name in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
+        _req(t, name=name)
+    _req(step, torch.int64, "step")
+    if not (p.numel() == g.numel() == m.numel() == v.numel()):
+        raise ValueError("adamw_step: p/g/m/v lengths differ")
+    check(lib().phnet_adamw_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), int(n_decay), _ptr(step), float(lr), float(beta1),
+                                 float(beta2), float(eps), float(weight_decay), _stream()), "phnet_adamw_step")
 
 
 def dropout_add(x, res=None, rng=None):

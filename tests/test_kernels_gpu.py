@@ -436,6 +436,42 @@ def test_attention_in_kernel_dropout_matches_explicit_mask(ops):
     assert not torch.equal(o1, o3) and not torch.equal(o1, o4) and torch.equal(o5, o6)
 
 
+def test_flat_adamw_matches_torch_adamw(ops):
+    """phnet_amd.optim.FlatAdamW (one launch over the flat arenas) against torch.optim.AdamW with the reference's grouping
+    (weight decay on matrices only), including a channels_last conv weight whose flat view keeps the OHWI strides."""
+    from phnet_amd.optim import FlatAdamW, split_decay
+
+    def make():
+        torch.manual_seed(4)
+        net = torch.nn.Sequential(torch.nn.Conv2d(8, 12, 3, bias=False), torch.nn.BatchNorm2d(12), torch.nn.Flatten(), torch.nn.Linear(12 * 36, 7)).cuda()      # (a conv bias in front of BN would have a pure-noise gradient, which Adam amplifies to +-lr)
+        net[0].weight.data = net[0].weight.data.contiguous(memory_format=torch.channels_last)
+        return net
+    ref, net = make(), make()
+    decay, no_decay = split_decay(ref.parameters())
+    kw = dict(lr=5e-3, betas=(0.9, 0.99), eps=1e-8)
+    topt = torch.optim.AdamW([{"params": decay, "weight_decay": 0.05}, {"params": no_decay, "weight_decay": 0.0}], **kw)
+    fopt, arena = FlatAdamW.for_model(net, weight_decay=0.05, **kw)
+    try:
+        assert not net[0].weight.is_contiguous() and net[0].weight.is_contiguous(memory_format=torch.channels_last)
+        assert (arena.numel + 3) // 4 * 4 == arena.flat.numel() == arena.flat_params.numel()
+        for step in range(4):
+            x = torch.randn(5, 8, 8, 8, device="cuda")
+            topt.zero_grad(set_to_none=True)
+            fopt.zero_grad()
+            ref(x).square().mean().backward()
+            loss = net(x).square().mean()
+            grads = torch.autograd.grad(loss, list(net.parameters()))
+            for p, gr in zip(net.parameters(), grads):
+                p.grad.add_(gr)                                      # what the HIP backward kernels do: accumulate into the arena
+            topt.step()
+            fopt.step()
+            for (k, a), b in zip(ref.named_parameters(), net.parameters()):
+                close(b, a, 2e-6)
+        assert int(fopt.step_count) == 4
+    finally:
+        arena.release()
+
+
 def test_memory_tokens_gate_tail_blend(ops):
     """The three small fused pieces of the per-frame loop against their tensor-op definitions."""
     torch.manual_seed(21)
