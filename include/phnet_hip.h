@@ -80,7 +80,8 @@ int phnet_conv2d_plan(int64_t M, int32_t Co, int32_t K, uint64_t ws_bytes, int32
 /* tuning aid for benchmarks only (process-global): force tile/split-K of the next fwd/dgrad calls; bm=0 -> heuristic. */
 int phnet_tune_force_conv_tile(int32_t bm, int32_t bn, int32_t splits);
 int phnet_tune_force_k_tile(int32_t k_tile);   /* 0 = heuristic, else 16 | 32 | 64; -1 / -2: uniform-tap kernel variant off / on */
-int phnet_tune_wgrad(int32_t allow_bm128, int32_t target_blocks);   /* wgrad tile / split-K policy */
+int phnet_tune_wgrad(int32_t allow_bm128, int32_t target_blocks);   /* wgrad tile / split-K policy; bit 1 of the first
+                                                                        argument disables the few-rows Linear kernel */
 uint64_t phnet_conv2d_wgrad_workspace(int32_t N, int32_t Hi, int32_t Wi, int32_t Ci, int32_t Co,
                                       int32_t R, int32_t S, int32_t stride, int32_t pad);
 /* dbias (optional, [Co]) = sum of dy over all pixels = the bias gradient, produced by the same launch. */

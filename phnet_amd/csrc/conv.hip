@@ -436,6 +436,96 @@ __global__ __launch_bounds__(THREADS) void conv_wgrad_kernel(
     }
 }
 
+// ---- weight gradient of a Linear layer over few rows (P <= 256: the M = 240 layers of the lane head) ------------------
+// dW[Co][Ci] (+)= dY^T X with the WHOLE reduction dimension staged in LDS at once: every global load of the workgroup is
+// in flight together (one memory latency instead of one per 16-row step - the generic loop needs ~2 us per step, and
+// splitting its 15 steps over workgroups costs a second launch), then 15 x 8 MFMAs back to back.  No split, no reduce:
+// the result goes (or accumulates) straight into the gradient arena.  The bias gradient is the column sum of the staged
+// dY tile.
+constexpr int SMALLP_MAX = 256;
+template <int BM, int BN>
+__global__ __launch_bounds__(THREADS) void linear_wgrad_smallp_kernel(
+    const float* __restrict__ dY, const float* __restrict__ X, float* __restrict__ dw, float* __restrict__ dbias,
+    int P, int Co, int Ci, int want_bias, int accumulate)
+{
+    constexpr int TM = BM / 2, TN = BN / 2, FM = TM / 32, FN = TN / 32;
+    constexpr int AP = BM + 4, BP = BN + 4;
+    constexpr int A_CH = BM / 4, B_CH = BN / 4;                     // float4 chunks per staged row
+    constexpr int A_LOADS = SMALLP_MAX * A_CH / THREADS, B_LOADS = SMALLP_MAX * B_CH / THREADS;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int P16 = (P + 15) & ~15;
+    float* As = lds;
+    float* Bs = lds + P16 * AP;
+    const int tiles_n = (Ci + BN - 1) / BN;
+    const unsigned tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (int)(tile / tiles_n) * BM, n0 = (int)(tile % tiles_n) * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * TM, wn = (wave & 1) * TN;
+
+    f32x4 ar[A_LOADS], br[B_LOADS];
+    unsigned am = 0, bm = 0;
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) {                            // branch-free: masked chunks read element 0
+        const int idx = tid + THREADS * i, p = idx / A_CH, m = m0 + (idx - p * A_CH) * 4;
+        const bool ok = p < P && m < Co;
+        ar[i] = *reinterpret_cast<const f32x4*>(dY + (ok ? (size_t)p * Co + m : 0));
+        am |= (unsigned)ok << i;
+    }
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i) {
+        const int idx = tid + THREADS * i, p = idx / B_CH, n = n0 + (idx - p * B_CH) * 4;
+        const bool ok = p < P && n < Ci;
+        br[i] = *reinterpret_cast<const f32x4*>(X + (ok ? (size_t)p * Ci + n : 0));
+        bm |= (unsigned)ok << i;
+    }
+    const f32x4 zero{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) {
+        const int idx = tid + THREADS * i, p = idx / A_CH;
+        if (p < P16) *reinterpret_cast<f32x4*>(As + p * AP + (idx - p * A_CH) * 4) = (am >> i) & 1u ? ar[i] : zero;
+    }
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i) {
+        const int idx = tid + THREADS * i, p = idx / B_CH;
+        if (p < P16) *reinterpret_cast<f32x4*>(Bs + p * BP + (idx - p * B_CH) * 4) = (bm >> i) & 1u ? br[i] : zero;
+    }
+    __syncthreads();
+
+    f32x16 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    for (int ks = 0; ks < P16 / BK; ++ks) {
+        float a[FM][8], b[FN][8];
+        read_kstrided<FM, AP>(As + wm, lane, ks, a);
+        read_kstrided<FN, BP>(Bs + wn, lane, ks, b);
+        mma_step<FM, FN>(a, b, acc);
+    }
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        const int n = n0 + wn + j * 32 + frag_col(lane);
+        if (n >= Ci) continue;
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm + i * 32 + frag_row(lane, e);
+                if (m < Co) {
+                    float* q = dw + (size_t)m * Ci + n;
+                    *q = accumulate ? *q + acc[i][j][e] : acc[i][j][e];
+                }
+            }
+    }
+    if (want_bias && n0 == 0 && tid < BM && m0 + tid < Co) {
+        float t = 0.f;
+        for (int p = 0; p < P16; ++p) t += As[p * AP + tid];
+        dbias[m0 + tid] = accumulate ? dbias[m0 + tid] + t : t;
+    }
+}
+
 // dW (+)= sum_z part[z][0:nw],  dbias (+)= sum_z part[z][nw:nw+nb]   (part rows are nw+nb floats long)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
                                                            float* __restrict__ dbias, long nw, long nb, int splits, int accumulate)
@@ -490,6 +580,7 @@ int g_force_bm = 0, g_force_bn = 0, g_force_splits = 0;      // tuning aid (phne
 int g_force_kt = 0;                                          // tuning aid (phnet_tune_force_k_tile)
 int g_uniform_tap = 1;                                       // tuning aid (phnet_tune_force_k_tile(-1) switches the uniform-tap variant off)
 int g_wgrad_bm128 = 1, g_wgrad_target = 768;                // tuning aids (phnet_tune_wgrad)
+int g_wgrad_smallp = 1;                                      // bit 1 of phnet_tune_wgrad's first argument switches the few-rows kernel off
 
 ConvPlan plan_conv(long M, int Co, int K, bool has_ws, size_t ws_bytes)
 {
@@ -591,7 +682,7 @@ PHNET_API int phnet_tune_force_conv_tile(int32_t bm, int32_t bn, int32_t splits)
 PHNET_API int phnet_tune_wgrad(int32_t allow_bm128, int32_t target_blocks)
 {
     if (target_blocks < 1) return PHNET_ERR_ARG;
-    g_wgrad_bm128 = allow_bm128; g_wgrad_target = target_blocks;
+    g_wgrad_bm128 = allow_bm128 & 1; g_wgrad_smallp = !(allow_bm128 & 2); g_wgrad_target = target_blocks;
     return PHNET_OK;
 }
 
@@ -688,6 +779,24 @@ PHNET_API int phnet_conv2d_wgrad(const float* dy, const float* x, float* dw, flo
     g.Wo = (Wi + 2 * pad - S) / stride + 1;
     const long P = (long)N * g.Ho * g.Wo, NC = (long)R * S * Ci;
     hipStream_t st = (hipStream_t)stream;
+    // Linear over few rows with few output tiles (with many tiles the generic kernel keeps several workgroups per CU in
+    // flight, which hides the same latency; this one needs 139 KB of LDS = one workgroup per CU)
+    if (R == 1 && S == 1 && stride == 1 && pad == 0 && P <= SMALLP_MAX && g_wgrad_smallp &&
+        ceil_div64(Co, 64) * ceil_div64(Ci, 64) < 64) {
+        const int P16 = ((int)P + 15) & ~15;
+        const size_t lds = (size_t)P16 * (64 + 4) * 2 * sizeof(float);
+        static bool attr = false;
+        if (lds > 64 * 1024 && !attr) {
+            if (hipFuncSetAttribute((const void*)linear_wgrad_smallp_kernel<64, 64>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)((size_t)SMALLP_MAX * 68 * 2 * sizeof(float))) != hipSuccess)
+                return PHNET_ERR_LAUNCH;
+            attr = true;
+        }
+        const long tiles = ceil_div64(Co, 64) * ceil_div64(Ci, 64);
+        hipLaunchKernelGGL((linear_wgrad_smallp_kernel<64, 64>), dim3((unsigned)tiles), dim3(THREADS), lds, st, dy, x, dw, dbias,
+                           (int)P, Co, Ci, dbias != nullptr, accumulate);
+        return phnet_launch_status();
+    }
     int bm = 64;
     const int bn = 64;
     long splits = wgrad_splits(P, Co, NC, &bm);
