@@ -185,7 +185,7 @@ int phnet_gate_stack_bwd(const float* gout, const float* x, const float* out, co
 
 /* ---- fused attention core (heads of width 16, Lq/Lk <= 256): replaces the scale/bmm/mask/softmax/dropout/bmm chain inside
  * nn.MultiheadAttention (libs/models/utils/transformer.py:275-298) and its backward.  q/k/v/o and the gradients are
- * addressed with row strides (floats), heads packed along the row.  key_valid u8[Lk] optional; keep u8[H][Lq][Lk]
+ * addressed with row strides (floats, multiples of 4, 16-byte aligned bases), heads packed along the row.  key_valid u8[Lk] optional; keep u8[H][Lq][Lk]
  * optional explicit dropout keep-mask (kept weights scaled by keep_scale); with keep == NULL, rng_state != NULL and
  * drop_p > 0 the mask is drawn in the kernel instead: element (h, q, k) of dropout site rng_call is kept iff a splitmix64
  * hash of (*rng_state, rng_call, element index) clears drop_p * 2^32, scale 1/(1-drop_p); the backward recomputes the

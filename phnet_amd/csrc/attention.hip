@@ -5,7 +5,7 @@
 // the 240 anchor queries, cross-attention to <= 40 memory tokens; 8 heads x 16): per attention, ATen issues
 // ~12 launches forward (scale, bmm, mask, softmax, dropout, bmm, transposes) and ~20 backward; here 1 + 2.
 // The problems are tiny (240 x 240 x 16 per head) and latency-bound: no MFMA, fp32 FMAs, K/V of one head staged in
-// LDS, 4 lanes per query row (online softmax per lane, merged with shuffles).
+// LDS, 16 lanes per query row (online softmax per lane, merged with shuffles).
 //
 // Tensors are addressed with row strides, so q/k/v may be column slices of a packed [L,3E] projection output and the
 // gradients are written straight into the packed gradient buffer.
@@ -15,27 +15,67 @@ namespace {
 
 constexpr int D = 16;                 // head width
 constexpr int NT = 256;
-constexpr int ROWS = NT / 4;          // 64 rows (queries or keys) per workgroup, 4 lanes each
+constexpr int LPR = 16;               // lanes per row: each walks every 16th key (or query) - the per-lane loop is the critical path
+constexpr int ROWS = NT / LPR;        // 16 rows (queries or keys) per workgroup -> 8 heads x 15 tiles = 120+ workgroups per launch
 constexpr int MAXK = 256;             // keys per head held in LDS
 
 struct AttnShape { int Lq, Lk, H; long sq, sk, sv, so; float scale, keep_scale; };
 
-// 4 adjacent lanes -> one row: reduce across them
-__device__ __forceinline__ float quad_sum(float v) { v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); return v; }
-__device__ __forceinline__ float quad_max(float v) { v = fmaxf(v, __shfl_xor(v, 1, 64)); return fmaxf(v, __shfl_xor(v, 2, 64)); }
+constexpr int DP = D + 4;              // LDS row pitch: 16-byte aligned rows (b128 access), 4 consecutive rows on distinct banks
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+// Stage head h of `rows` rows (<= MAXK) of two row-strided arrays into LDS.  All global loads are issued before the first
+// LDS store (branch-free, clamped addresses): one memory latency for the whole tile instead of one per loop trip.
+__device__ __forceinline__ void stage_pair(const float* __restrict__ a, long sa, const float* __restrict__ b, long sb, int h, int rows,
+                                           float (*As)[DP], float (*Bs)[DP], float a_scale)
+{
+    constexpr int N = MAXK * (D / 4) / NT;      // float4 chunks per thread and array
+    f4 ra[N], rb[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const int idx = threadIdx.x + NT * i, r = idx >> 2, c = (idx & 3) * 4;
+        const int rr = r < rows ? r : 0;
+        ra[i] = *reinterpret_cast<const f4*>(a + (size_t)rr * sa + h * D + c);
+        rb[i] = *reinterpret_cast<const f4*>(b + (size_t)rr * sb + h * D + c);
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const int idx = threadIdx.x + NT * i, r = idx >> 2, c = (idx & 3) * 4;
+        if (r < rows) {
+            *reinterpret_cast<f4*>(&As[r][c]) = ra[i] * a_scale;
+            *reinterpret_cast<f4*>(&Bs[r][c]) = rb[i];
+        }
+    }
+}
+
+// 16-wide dot products with four independent partial sums (a single chain of 16 dependent FMAs is pure latency here)
+__device__ __forceinline__ float dot16(const float (&a)[D], const float* b) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+    for (int d = 0; d < D; d += 4) { s0 += a[d] * b[d]; s1 += a[d + 1] * b[d + 1]; s2 += a[d + 2] * b[d + 2]; s3 += a[d + 3] * b[d + 3]; }
+    return (s0 + s1) + (s2 + s3);
+}
+
+// LPR adjacent lanes -> one row: reduce across them
+__device__ __forceinline__ float quad_sum(float v) {
+#pragma unroll
+    for (int o = 1; o < LPR; o <<= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float quad_max(float v) {
+#pragma unroll
+    for (int o = 1; o < LPR; o <<= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
 
 __global__ __launch_bounds__(NT) void attn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
                                                       const unsigned char* __restrict__ key_valid, const unsigned char* __restrict__ keep,
                                                       float* __restrict__ o, float* __restrict__ lse, AttnShape g, DropRng rng)
 {
-    __shared__ float Ks[MAXK][D + 1], Vs[MAXK][D + 1];
+    __shared__ __attribute__((aligned(16))) float Ks[MAXK][DP], Vs[MAXK][DP];
     __shared__ unsigned char valid[MAXK];
-    const int h = blockIdx.x, row = blockIdx.y * ROWS + (threadIdx.x >> 2), part = threadIdx.x & 3;
-    for (int i = threadIdx.x; i < g.Lk * D; i += NT) {
-        const int kk = i / D, d = i - kk * D;
-        Ks[kk][d] = k[(size_t)kk * g.sk + h * D + d];
-        Vs[kk][d] = v[(size_t)kk * g.sv + h * D + d];
-    }
+    const int h = blockIdx.x, row = blockIdx.y * ROWS + threadIdx.x / LPR, part = threadIdx.x % LPR;
+    stage_pair(k, g.sk, v, g.sv, h, g.Lk, Ks, Vs, 1.0f);
     for (int i = threadIdx.x; i < g.Lk; i += NT) valid[i] = key_valid ? key_valid[i] : 1;
     __syncthreads();
     const bool live = row < g.Lq;
@@ -47,11 +87,9 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(const float* __restrict__ 
     for (int d = 0; d < D; ++d) acc[d] = 0.f;
     const unsigned char* kp = keep ? keep + ((size_t)h * g.Lq + (live ? row : 0)) * g.Lk : nullptr;
     const uint64_t seed = phnet_rng_seed(rng), rbase = ((uint64_t)h * g.Lq + (live ? row : 0)) * g.Lk;
-    for (int kk = part; kk < g.Lk; kk += 4) {
+    for (int kk = part; kk < g.Lk; kk += LPR) {
         if (!valid[kk]) continue;
-        float s = 0.f;
-#pragma unroll
-        for (int d = 0; d < D; ++d) s += qr[d] * Ks[kk][d];
+        const float s = dot16(qr, Ks[kk]);
         const float mn = fmaxf(m, s);
         const float c = expf(m - mn), e = expf(s - mn);
         l = l * c + e;
@@ -61,7 +99,7 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(const float* __restrict__ 
         for (int d = 0; d < D; ++d) acc[d] = acc[d] * c + ed * Vs[kk][d];
         m = mn;
     }
-    // merge the 4 partial (m, l, acc) of the row
+    // merge the LPR partial (m, l, acc) of the row
     const float mt = quad_max(m);
     const float c = (m == -INFINITY) ? 0.f : expf(m - mt);
     l = quad_sum(l * c);
@@ -84,20 +122,16 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(const float* __restrict__ 
                                                       AttnShape g, long sdq, long sdk, long sdv, int q_tiles, DropRng rng)
 {
     const uint64_t seed = phnet_rng_seed(rng);
-    __shared__ float As[MAXK][D + 1], Bs[MAXK][D + 1];     // role 0: K, V of the head; role 1: Q*scale, dO of the head
+    __shared__ __attribute__((aligned(16))) float As[MAXK][DP], Bs[MAXK][DP];     // role 0: K, V of the head; role 1: Q*scale, dO
     __shared__ float Dl[MAXK], Ls[MAXK];                   // role 1: rowsum(dO*O), lse per query
     __shared__ unsigned char valid[MAXK];
     const int h = blockIdx.x;
     const bool dq_role = (int)blockIdx.y < q_tiles;
     const int tile = dq_role ? blockIdx.y : blockIdx.y - q_tiles;
-    const int row = tile * ROWS + (threadIdx.x >> 2), part = threadIdx.x & 3;
+    const int row = tile * ROWS + threadIdx.x / LPR, part = threadIdx.x % LPR;
     for (int i = threadIdx.x; i < g.Lk; i += NT) valid[i] = key_valid ? key_valid[i] : 1;
     if (dq_role) {
-        for (int i = threadIdx.x; i < g.Lk * D; i += NT) {
-            const int kk = i / D, d = i - kk * D;
-            As[kk][d] = k[(size_t)kk * g.sk + h * D + d];
-            Bs[kk][d] = v[(size_t)kk * g.sv + h * D + d];
-        }
+        stage_pair(k, g.sk, v, g.sv, h, g.Lk, As, Bs, 1.0f);
         __syncthreads();
         const bool live = row < g.Lq;
         const int r = live ? row : 0;
@@ -114,11 +148,10 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(const float* __restrict__ 
         float acc[D];
 #pragma unroll
         for (int d = 0; d < D; ++d) acc[d] = 0.f;
-        for (int kk = part; kk < g.Lk; kk += 4) {
+        for (int kk = part; kk < g.Lk; kk += LPR) {
             if (!valid[kk]) continue;
-            float s = 0.f, dp = 0.f;
-#pragma unroll
-            for (int d = 0; d < D; ++d) { s += qr[d] * As[kk][d]; dp += dor[d] * Bs[kk][d]; }
+            const float s = dot16(qr, As[kk]);
+            float dp = dot16(dor, Bs[kk]);
             const float p = expf(s - L);
             const bool kept = kp ? kp[kk] != 0 : (!rng.thresh || phnet_rng_keep(seed, rbase + kk, rng.thresh));
             dp = kept ? dp * g.keep_scale : 0.f;
@@ -133,11 +166,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(const float* __restrict__ 
             for (int d = 0; d < D; ++d) dq[(size_t)row * sdq + h * D + d] = acc[d] * g.scale;
     } else {
         // stage Q*scale, dO, delta, lse of ALL queries of this head (Lq <= MAXK)
-        for (int i = threadIdx.x; i < g.Lq * D; i += NT) {
-            const int qq = i / D, d = i - qq * D;
-            As[qq][d] = q[(size_t)qq * g.sq + h * D + d] * g.scale;
-            Bs[qq][d] = dout[(size_t)qq * g.so + h * D + d];
-        }
+        stage_pair(q, g.sq, dout, g.so, h, g.Lq, As, Bs, g.scale);
         __syncthreads();
         for (int qq = threadIdx.x; qq < g.Lq; qq += NT) {
             float s = 0.f;
@@ -158,10 +187,8 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(const float* __restrict__ 
         }
         const bool kvalid = live && valid[r];
         if (kvalid)
-            for (int qq = part; qq < g.Lq; qq += 4) {
-                float s = 0.f, dp = 0.f;
-#pragma unroll
-                for (int d = 0; d < D; ++d) { s += As[qq][d] * kr[d]; dp += Bs[qq][d] * vr[d]; }
+            for (int qq = part; qq < g.Lq; qq += LPR) {
+                const float s = dot16(kr, As[qq]), dp = dot16(vr, Bs[qq]);
                 const float p = expf(s - Ls[qq]);
                 const uint64_t ei = ((uint64_t)h * g.Lq + qq) * g.Lk + r;
                 const bool kept = keep ? keep[ei] != 0 : (!rng.thresh || phnet_rng_keep(seed, ei, rng.thresh));
@@ -182,6 +209,8 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(const float* __restrict__ 
 }
 
 bool attn_ok(int Lq, int Lk, int H, int E) { return Lq >= 1 && Lk >= 1 && Lq <= MAXK && Lk <= MAXK && H >= 1 && E == H * D; }
+// float4 staging: rows 16-byte aligned
+bool aligned16(const void* p, int64_t stride) { return ((uintptr_t)p & 15) == 0 && (stride & 3) == 0; }
 
 }  // namespace
 
@@ -195,6 +224,7 @@ PHNET_API int phnet_attention_fwd(const float* q, const float* k, const float* v
                                   const uint64_t* rng_state, uint64_t rng_call, float drop_p, void* stream)
 {
     if (!attn_ok(Lq, Lk, H, E) || !q || !k || !v || !o || !lse || drop_p < 0.f || drop_p >= 1.f) return PHNET_ERR_ARG;
+    if (!aligned16(k, sk) || !aligned16(v, sv)) return PHNET_ERR_ARG;
     const DropRng rng = keep ? DropRng{nullptr, 0, 0u} : phnet_make_rng(rng_state, rng_call, drop_p);
     AttnShape g{Lq, Lk, H, sq, sk, sv, so, 1.0f / sqrtf((float)D), keep ? keep_scale : (rng.thresh ? 1.0f / (1.0f - drop_p) : 1.0f)};
     hipLaunchKernelGGL(attn_fwd_kernel, dim3(H, (Lq + ROWS - 1) / ROWS), dim3(NT), 0, (hipStream_t)stream,
@@ -211,6 +241,7 @@ PHNET_API int phnet_attention_bwd(const float* q, const float* k, const float* v
 {
     if (!attn_ok(Lq, Lk, H, E) || !q || !k || !v || !o || !dout || !lse || !dq || !dk || !dv || drop_p < 0.f || drop_p >= 1.f)
         return PHNET_ERR_ARG;
+    if (!aligned16(k, sk) || !aligned16(v, sv) || !aligned16(q, sq) || !aligned16(dout, so)) return PHNET_ERR_ARG;
     const DropRng rng = keep ? DropRng{nullptr, 0, 0u} : phnet_make_rng(rng_state, rng_call, drop_p);
     AttnShape g{Lq, Lk, H, sq, sk, sv, so, 1.0f / sqrtf((float)D), keep ? keep_scale : (rng.thresh ? 1.0f / (1.0f - drop_p) : 1.0f)};
     const int qt = (Lq + ROWS - 1) / ROWS, kt = (Lk + ROWS - 1) / ROWS;
