@@ -519,10 +519,19 @@ __global__ __launch_bounds__(THREADS) void linear_wgrad_smallp_kernel(
                 }
             }
     }
-    if (want_bias && n0 == 0 && tid < BM && m0 + tid < Co) {
+    if (want_bias && n0 == 0) {                                      // column sums of the staged dY tile: 4 row groups, then fold
+        static_assert(BM == 64, "bias fold assumes 64 columns x 4 row groups");
+        const int c = tid & 63, grp = tid >> 6;
         float t = 0.f;
-        for (int p = 0; p < P16; ++p) t += As[p * AP + tid];
-        dbias[m0 + tid] = accumulate ? dbias[m0 + tid] + t : t;
+#pragma unroll 4
+        for (int p = grp; p < P16; p += 4) t += As[p * AP + c];
+        __syncthreads();                                            // every wave is done with the MFMA reads of Bs
+        Bs[grp * 64 + c] = t;
+        __syncthreads();
+        if (tid < 64 && m0 + tid < Co) {
+            const float v = (Bs[tid] + Bs[64 + tid]) + (Bs[128 + tid] + Bs[192 + tid]);
+            dbias[m0 + tid] = accumulate ? dbias[m0 + tid] + v : v;
+        }
     }
 }
 
