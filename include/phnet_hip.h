@@ -230,6 +230,17 @@ int phnet_blend_priors(const float* gate, const float* a, const float* b, const 
 int phnet_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, int64_t n_decay, const int64_t* step,
                      float lr, float beta1, float beta2, float eps, float weight_decay, void* stream);
 
+/* residual + dropout + LayerNorm of the pre-norm decoder layers in one launch: t = res + dropout(x), h = LN_L(t)*w + b
+ * (L <= 256), and its backward (dt = gradient arriving on the residual stream, may be NULL): dres, dx, dw, db. */
+int phnet_dropout_add_ln_fwd(const float* x, const float* res, const float* w, const float* b, float* t, float* h,
+                             float* mean, float* rstd, int64_t rows, int32_t L, float eps,
+                             const uint64_t* rng_state, uint64_t rng_call, float drop_p, void* stream);
+int phnet_dropout_add_ln_bwd(const float* dh, const float* dt, const float* t, const float* w, const float* mean,
+                             const float* rstd, float* dres, float* dx, float* dw, float* db,
+                             int64_t rows, int32_t L, int32_t param_accumulate,
+                             const uint64_t* rng_state, uint64_t rng_call, float drop_p,
+                             void* workspace, uint64_t ws_bytes, void* stream);
+
 /* ---- per-anchor dynamic convolution: y[n] = relu(LayerNorm_J(x[n] @ w[n]) * gamma + beta), replacing torch.bmm + norm1/norm2
  * + ReLU in libs/models/utils/dynamic_head.py:40-51 (and their backward).  x [N][P][K], w [N][K][J] (generated per anchor),
  * y [N][P][J], stats [N][P][2] = (mean, rstd) (NULL = inference).  J <= 128; J and K divide 256.  Backward: dx optional,

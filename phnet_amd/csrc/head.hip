@@ -211,6 +211,101 @@ __global__ __launch_bounds__(NT) void layernorm_bwd_short_kernel(
     }
 }
 
+// ---- residual + dropout + LayerNorm of the pre-norm transformer (utils/transformer.py:275-298), L <= 256 ----------------
+//   t = res + dropout(x);  h = LayerNorm(t) * w + b       -> both written (t is the running stream, h feeds the next block)
+// The dropout bit of element i of the [rows][L] array comes from the counter-based generator of common.h.
+__global__ __launch_bounds__(NT) void dropout_add_ln_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ res, const float* __restrict__ w, const float* __restrict__ b,
+    float* __restrict__ t_out, float* __restrict__ h_out, float* __restrict__ mean, float* __restrict__ rstd,
+    long rows, int L, float eps, DropRng rng, float scale)
+{
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const size_t o = (size_t)row * L;
+    const uint64_t seed = phnet_rng_seed(rng);
+    float t[SHORT_MAX_L / 64], s = 0.f;
+#pragma unroll
+    for (int u = 0; u < SHORT_MAX_L / 64; ++u) {
+        const int i = lane + 64 * u;
+        t[u] = 0.f;
+        if (i < L) {
+            const bool kept = !rng.thresh || phnet_rng_keep(seed, (uint64_t)(o + i), rng.thresh);
+            t[u] = res[o + i] + (kept ? x[o + i] * scale : 0.f);
+            t_out[o + i] = t[u];
+            s += t[u];
+        }
+    }
+    const float mu = wave_sum(s) / (float)L;
+    float v = 0.f;
+#pragma unroll
+    for (int u = 0; u < SHORT_MAX_L / 64; ++u) {
+        const int i = lane + 64 * u;
+        if (i < L) { const float d = t[u] - mu; v += d * d; }
+    }
+    const float rs = 1.0f / sqrtf(wave_sum(v) / (float)L + eps);
+    if (lane == 0 && mean) { mean[row] = mu; rstd[row] = rs; }
+#pragma unroll
+    for (int u = 0; u < SHORT_MAX_L / 64; ++u) {
+        const int i = lane + 64 * u;
+        if (i < L) h_out[o + i] = (t[u] - mu) * rs * w[i] + b[i];
+    }
+}
+
+// backward: g = LayerNorm'(dh) + dt (dt optional);  dres = g;  dx = dropout'(g);  affine partials as in the short kernel
+__global__ __launch_bounds__(NT) void dropout_add_ln_bwd_kernel(
+    const float* __restrict__ dh, const float* __restrict__ dt, const float* __restrict__ t, const float* __restrict__ w,
+    const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ dres, float* __restrict__ dx,
+    float* __restrict__ partial, long rows, int L, long rows_per_slab, DropRng rng, float scale)
+{
+    __shared__ float red[2][NT / 64][SHORT_MAX_L];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long a = (long)blockIdx.x * rows_per_slab, e = min(rows, a + rows_per_slab);
+    const uint64_t seed = phnet_rng_seed(rng);
+    float pw[SHORT_MAX_L / 64], pb[SHORT_MAX_L / 64];
+#pragma unroll
+    for (int u = 0; u < SHORT_MAX_L / 64; ++u) { pw[u] = 0.f; pb[u] = 0.f; }
+    for (long row = a + wave; row < e; row += NT / 64) {
+        const size_t o = (size_t)row * L;
+        const float mu = mean[row], rs = rstd[row];
+        float g[SHORT_MAX_L / 64], xh[SHORT_MAX_L / 64], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int u = 0; u < SHORT_MAX_L / 64; ++u) {
+            const int i = lane + 64 * u;
+            g[u] = 0.f; xh[u] = 0.f;
+            if (i < L) {
+                g[u] = dh[o + i];
+                xh[u] = (t[o + i] - mu) * rs;
+                const float gw = g[u] * w[i];
+                s1 += gw;
+                s2 += gw * xh[u];
+                pw[u] += g[u] * xh[u];
+                pb[u] += g[u];
+            }
+        }
+        s1 = wave_sum(s1) / (float)L;
+        s2 = wave_sum(s2) / (float)L;
+#pragma unroll
+        for (int u = 0; u < SHORT_MAX_L / 64; ++u) {
+            const int i = lane + 64 * u;
+            if (i < L) {
+                float gt = rs * (g[u] * w[i] - s1 - xh[u] * s2);
+                if (dt) gt += dt[o + i];
+                dres[o + i] = gt;
+                const bool kept = !rng.thresh || phnet_rng_keep(seed, (uint64_t)(o + i), rng.thresh);
+                dx[o + i] = kept ? gt * scale : 0.f;
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < SHORT_MAX_L / 64; ++u) { red[0][wave][lane + 64 * u] = pw[u]; red[1][wave][lane + 64 * u] = pb[u]; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * L; i += NT) {
+        const int which = i / L, c = i - which * L;
+        partial[((size_t)blockIdx.x * 2 + which) * L + c] = (red[which][0][c] + red[which][1][c]) + (red[which][2][c] + red[which][3][c]);
+    }
+}
+
 // partial[slab][0][L] = sum_rows g*xhat, partial[slab][1][L] = sum_rows g   (rows of this slab)
 __global__ __launch_bounds__(NT) void layernorm_bwd_param_partial_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y,
@@ -416,5 +511,42 @@ PHNET_API int phnet_dwconv3x3_wgrad(const float* dy, const float* x, float* dw, 
     if (!dy || !x || !dw || !db) return PHNET_ERR_ARG;
     hipLaunchKernelGGL(dwconv3x3_wgrad_kernel, dim3(N), dim3(NT), (size_t)C * P * 4, (hipStream_t)stream, dy, x, dw, db, C, P,
                        accumulate);
+    return phnet_launch_status();
+}
+
+// t = res + dropout(x), h = LayerNorm_L(t) * w + b in one launch (L <= 256); mean/rstd [rows] saved for the backward.
+PHNET_API int phnet_dropout_add_ln_fwd(const float* x, const float* res, const float* w, const float* b, float* t, float* h,
+                                       float* mean, float* rstd, int64_t rows, int32_t L, float eps,
+                                       const uint64_t* rng_state, uint64_t rng_call, float drop_p, void* stream)
+{
+    if (rows < 0 || L < 1 || L > SHORT_MAX_L || drop_p < 0.f || drop_p >= 1.f) return PHNET_ERR_ARG;
+    if (rows == 0) return PHNET_OK;
+    if (!x || !res || !w || !b || !t || !h) return PHNET_ERR_ARG;
+    const DropRng rng = phnet_make_rng(rng_state, rng_call, drop_p);
+    hipLaunchKernelGGL(dropout_add_ln_fwd_kernel, dim3((unsigned)ceil_div64(rows, NT / 64)), dim3(NT), 0, (hipStream_t)stream,
+                       x, res, w, b, t, h, mean, rstd, (long)rows, L, eps, rng, rng.thresh ? 1.0f / (1.0f - drop_p) : 1.0f);
+    return phnet_launch_status();
+}
+
+// Backward of phnet_dropout_add_ln_fwd: dh = dL/dh, dt = dL/dt from the residual stream (may be NULL) ->
+// dres [rows][L] (gradient of res), dx (gradient of x, same dropout bits), dw/db [L] overwritten or accumulated.
+// workspace: phnet_layernorm_bwd_workspace(rows, L) bytes.
+PHNET_API int phnet_dropout_add_ln_bwd(const float* dh, const float* dt, const float* t, const float* w, const float* mean,
+                                       const float* rstd, float* dres, float* dx, float* dw, float* db,
+                                       int64_t rows, int32_t L, int32_t param_accumulate,
+                                       const uint64_t* rng_state, uint64_t rng_call, float drop_p,
+                                       void* workspace, uint64_t ws_bytes, void* stream)
+{
+    if (rows < 0 || L < 1 || L > SHORT_MAX_L || drop_p < 0.f || drop_p >= 1.f) return PHNET_ERR_ARG;
+    if (rows == 0) return PHNET_OK;
+    if (!dh || !t || !w || !mean || !rstd || !dres || !dx || !dw || !db || !workspace) return PHNET_ERR_ARG;
+    const long slabs = max((long)1, min((long)128, ceil_div64(rows, 8)));
+    if ((uint64_t)(slabs * 2 * L * sizeof(float)) > ws_bytes) return PHNET_ERR_WORKSPACE;
+    const DropRng rng = phnet_make_rng(rng_state, rng_call, drop_p);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(dropout_add_ln_bwd_kernel, dim3((unsigned)slabs), dim3(NT), 0, st, dh, dt, t, w, mean, rstd, dres, dx,
+                       (float*)workspace, (long)rows, L, ceil_div64(rows, slabs), rng, rng.thresh ? 1.0f / (1.0f - drop_p) : 1.0f);
+    hipLaunchKernelGGL(layernorm_bwd_param_finalize_kernel, dim3((L + 255) / 256), dim3(256), 0, st,
+                       (const float*)workspace, dw, db, (int)slabs, L, param_accumulate);
     return phnet_launch_status();
 }

@@ -335,6 +335,46 @@ def dropout_add(res, x, p: float = 0.0):
     return _DropoutAdd.apply(res, x, p)
 
 
+class _DropoutAddLN(torch.autograd.Function):
+    """(t, h) = (res + dropout(x), LayerNorm(t)): the residual update of a pre-norm decoder block together with the
+    LayerNorm that opens the next block, one launch forward, one (+ the small finalize) backward - the backward also
+    absorbs the fan-in add of the two consumers of t."""
+
+    @staticmethod
+    def forward(ctx, res, x, w, b, p, eps):
+        ctx.set_materialize_grads(False)
+        ctx.rng = DropoutStream.site(x.device, p)
+        wf, bf = w.reshape(-1).contiguous(), b.reshape(-1).contiguous()
+        need = any(ctx.needs_input_grad)
+        t, h, mean, rstd = K.dropout_add_ln_fwd(x.contiguous(), res.contiguous(), wf, bf, eps, ctx.rng, save_stats=need)
+        if need:
+            ctx.save_for_backward(t, wf, mean, rstd)
+        ctx.wshape = w.shape
+        ctx.w_direct, ctx.b_direct = direct_grad(w), direct_grad(b)
+        return t, h
+
+    @staticmethod
+    def backward(ctx, dt, dh):
+        t, w, mean, rstd = ctx.saved_tensors
+        if dh is None:                                            # only the residual stream was used downstream
+            if dt is None:
+                return None, None, None, None, None, None
+            dx = dt if ctx.rng is None else K.dropout_add(dt.contiguous(), None, ctx.rng)
+            return dt, dx, None, None, None, None
+        dtc = None if dt is None else dt.contiguous()
+        if ctx.w_direct is not None and ctx.b_direct is not None:
+            dres, dx, _, _ = K.dropout_add_ln_bwd(dh.contiguous(), dtc, t, w, mean, rstd, ctx.rng,
+                                                  dw=ctx.w_direct.view(-1), db=ctx.b_direct.view(-1), accumulate=True)
+            return dres, dx, None, None, None, None
+        dres, dx, dw, db = K.dropout_add_ln_bwd(dh.contiguous(), dtc, t, w, mean, rstd, ctx.rng)
+        return dres, dx, dw.view(ctx.wshape), db.view(ctx.wshape), None, None
+
+
+def dropout_add_ln(res, x, w, b, p: float = 0.0, eps: float = 1e-5):
+    """Returns (res + dropout(x), LayerNorm(res + dropout(x)) * w + b)."""
+    return _DropoutAddLN.apply(res, x, w, b, p, eps)
+
+
 class _GeluDropout(torch.autograd.Function):
     """dropout(gelu(x)), exact (erf) GELU, one launch each way."""
 

@@ -619,6 +619,35 @@ def dropout_add(x, res=None, rng=None):
     return y
 
 
+def dropout_add_ln_fwd(x, res, w, b, eps: float, rng=None, save_stats: bool = True):
+    """t = res + dropout(x), h = LayerNorm(t)*w + b over the last w.numel() (<= 256) elements -> (t, h, mean, rstd)."""
+    _req(x, name="x"); _req(res, name="res")
+    L = w.numel()
+    rows = x.numel() // L
+    t, h = torch.empty_like(x), torch.empty_like(x)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
+    check(lib().phnet_dropout_add_ln_fwd(_ptr(x), _ptr(res), _ptr(w), _ptr(b), _ptr(t), _ptr(h), _ptr(mean), _ptr(rstd), rows, L, eps,
+                                         *_rng_args(rng), _stream()), "phnet_dropout_add_ln_fwd")
+    return t, h, mean, rstd
+
+
+def dropout_add_ln_bwd(dh, dt, t, w, mean, rstd, rng=None, dw: Optional[torch.Tensor] = None, db: Optional[torch.Tensor] = None,
+                       accumulate: bool = False):
+    """Returns (dres, dx, dw, db); dt (gradient on the residual stream) may be None."""
+    _req(dh, name="dh")
+    L = w.numel()
+    rows = t.numel() // L
+    dres, dx = torch.empty_like(t), torch.empty_like(t)
+    if dw is None:
+        dw, db, accumulate = torch.empty_like(w), torch.empty_like(w), False
+    ws = workspace(lib().phnet_layernorm_bwd_workspace(rows, L), t.device, 2)
+    check(lib().phnet_dropout_add_ln_bwd(_ptr(dh), _ptr(dt), _ptr(t), _ptr(w), _ptr(mean), _ptr(rstd), _ptr(dres), _ptr(dx), _ptr(dw),
+                                         _ptr(db), rows, L, int(accumulate), *_rng_args(rng), _ptr(ws), ws.numel(), _stream()),
+          "phnet_dropout_add_ln_bwd")
+    return dres, dx, dw, db
+
+
 def gelu_dropout_fwd(x, rng=None):
     _req(x, name="x")
     y = torch.empty_like(x)

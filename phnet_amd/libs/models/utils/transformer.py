@@ -38,16 +38,22 @@ class TransformerDecoderLayer(nn.Module):
         self.dropout1, self.dropout2, self.dropout3 = nn.Dropout(dropout), nn.Dropout(dropout), nn.Dropout(dropout)
         self.normalize_before = normalize_before
 
-    def forward(self, tgt: torch.Tensor, memory: torch.Tensor, memory_key_valid=None) -> torch.Tensor:
-        """tgt [L,E], memory [M,E], memory_key_valid bool[M] or None."""
+    def forward(self, tgt: torch.Tensor, memory: torch.Tensor, memory_key_valid=None, h=None, next_norm=None):
+        """tgt [L,E], memory [M,E], memory_key_valid bool[M] or None.  h = norm1(tgt) if the caller already has it.
+        Every residual update is fused with the LayerNorm that follows it (norm2, norm3, and `next_norm` = the next
+        layer's norm1 or the decoder's final norm).  Returns (tgt_out, next_norm(tgt_out) or None)."""
         p = lambda d: d.p if self.training else 0.0                                  # noqa: E731
-        h = PF.layer_norm(tgt, self.norm1.weight, self.norm1.bias, eps=self.norm1.eps)
-        tgt = PF.dropout_add(tgt, _attention(self.self_attn, h, h, self.training), p(self.dropout1))
-        h = PF.layer_norm(tgt, self.norm2.weight, self.norm2.bias, eps=self.norm2.eps)
-        tgt = PF.dropout_add(tgt, _attention(self.multihead_attn, h, memory, self.training, memory_key_valid), p(self.dropout2))
-        h = PF.layer_norm(tgt, self.norm3.weight, self.norm3.bias, eps=self.norm3.eps)
+        if h is None:
+            h = PF.layer_norm(tgt, self.norm1.weight, self.norm1.bias, eps=self.norm1.eps)
+        tgt, h = PF.dropout_add_ln(tgt, _attention(self.self_attn, h, h, self.training),
+                                   self.norm2.weight, self.norm2.bias, p(self.dropout1), self.norm2.eps)
+        tgt, h = PF.dropout_add_ln(tgt, _attention(self.multihead_attn, h, memory, self.training, memory_key_valid),
+                                   self.norm3.weight, self.norm3.bias, p(self.dropout2), self.norm3.eps)
         h = PF.gelu_dropout(PF.linear(h, self.linear1.weight, self.linear1.bias), p(self.dropout))
-        return PF.dropout_add(tgt, PF.linear(h, self.linear2.weight, self.linear2.bias), p(self.dropout3))
+        f = PF.linear(h, self.linear2.weight, self.linear2.bias)
+        if next_norm is None:
+            return PF.dropout_add(tgt, f, p(self.dropout3)), None
+        return PF.dropout_add_ln(tgt, f, next_norm.weight, next_norm.bias, p(self.dropout3), next_norm.eps)
 
 
 class TransformerDecoder(nn.Module):
@@ -62,8 +68,8 @@ class TransformerDecoder(nn.Module):
         """tgt [L,1,E] or [L,E]; memory [M,1,E] or [M,E]; memory_key_valid bool[M]; returns the same rank as tgt."""
         shape = tgt.shape
         x, mem = tgt.reshape(shape[0], shape[-1]), memory.reshape(memory.shape[0], memory.shape[-1])
-        for layer in self.layers:
-            x = layer(x, mem, memory_key_valid)
-        if self.norm is not None:
-            x = PF.layer_norm(x, self.norm.weight, self.norm.bias, eps=self.norm.eps)
-        return x.reshape(shape)
+        h = None
+        for i, layer in enumerate(self.layers):
+            nxt = self.layers[i + 1].norm1 if i + 1 < len(self.layers) else self.norm
+            x, h = layer(x, mem, memory_key_valid, h=h, next_norm=nxt)
+        return (h if self.norm is not None else x).reshape(shape)

@@ -472,6 +472,40 @@ def test_flat_adamw_matches_torch_adamw(ops):
         arena.release()
 
 
+@pytest.mark.parametrize("L", [128, 64, 200])
+def test_dropout_add_layernorm_fused(ops, L):
+    """t = res + dropout(x), h = LN(t): exact vs torch at p = 0 (values and all gradients, with and without a gradient on
+    the residual stream); at p > 0 the backward redraws the forward's mask and kept entries carry the 1/(1-p) scale."""
+    torch.manual_seed(L)
+    rows = 240
+    x = torch.randn(rows, L, dtype=torch.float64, requires_grad=True)
+    res = torch.randn(rows, L, dtype=torch.float64, requires_grad=True)
+    w = (torch.rand(L, dtype=torch.float64) + 0.5).requires_grad_(True)
+    b = torch.randn(L, dtype=torch.float64, requires_grad=True)
+    t_ref = res + x
+    h_ref = F.layer_norm(t_ref, [L], w, b, 1e-5)
+    dt, dh = torch.randn_like(t_ref), torch.randn_like(h_ref)
+    (t_ref * dt).sum().add((h_ref * dh).sum()).backward()
+    xd, rd, wd, bd = (dev(v.detach().float()) for v in (x, res, w, b))
+    t, h, mean, rstd = ops.dropout_add_ln_fwd(xd, rd, wd, bd, 1e-5)
+    close(t, t_ref, 1e-6); close(h, h_ref, 2e-5)
+    dres, dx, dw, db = ops.dropout_add_ln_bwd(dev(dh.float()), dev(dt.float()), t, wd, mean, rstd)
+    close(dres, res.grad, 3e-5); close(dx, x.grad, 3e-5); close(dw, w.grad, 3e-5); close(db, b.grad, 3e-5)
+    dres0, dx0, _, _ = ops.dropout_add_ln_bwd(dev(dh.float()), None, t, wd, mean, rstd)
+    close(dres0, res.grad - dt, 3e-5)
+    assert torch.equal(dres0, dx0)
+    p = 0.3
+    rng = _rng(77, 5, p)
+    t2, h2, mean2, rstd2 = ops.dropout_add_ln_fwd(xd, rd, wd, bd, 1e-5, rng)
+    kept = (t2 - rd) != 0
+    assert abs(float(kept.float().mean()) - (1 - p)) < 0.02
+    close((t2 - rd)[kept], (xd / (1 - p))[kept], 1e-5)
+    close(h2, F.layer_norm(t2.double().cpu(), [L], w.detach(), b.detach(), 1e-5), 2e-5)
+    dres2, dx2, _, _ = ops.dropout_add_ln_bwd(dev(dh.float()), dev(dt.float()), t2, wd, mean2, rstd2, rng)
+    assert torch.equal(dx2 != 0, kept & (dres2 != 0))
+    close(dx2[kept], (dres2 / (1 - p))[kept], 1e-5)
+
+
 def test_memory_tokens_gate_tail_blend(ops):
     """The three small fused pieces of the per-frame loop against their tensor-op definitions."""
     torch.manual_seed(21)
