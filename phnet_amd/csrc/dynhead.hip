@@ -199,21 +199,23 @@ __global__ __launch_bounds__(NT) void dyn_bwd_kernel(const float* __restrict__ d
     }
 }
 
-// dgamma/dbeta (+)= sum over anchors of lnpart [N][2][J]: 2J columns x (1024 / 2J) anchor groups, folded through LDS
+// dgamma/dbeta (+)= sum over anchors of lnpart [N][2][J]: a workgroup owns 32 of the 2J columns, 32 anchor groups walk the
+// rows (8 loads per thread for N = 240 instead of 60: the loop is pure load latency) and are folded through LDS
 __global__ __launch_bounds__(1024) void dyn_ln_grad_reduce_kernel(const float* __restrict__ lnpart, float* __restrict__ dgamma,
                                                                  float* __restrict__ dbeta, int N, int J, int accumulate)
 {
-    __shared__ float part[1024];
-    const int cols = 2 * J, groups = 1024 / cols;
-    const int c = threadIdx.x % cols, grp = threadIdx.x / cols;
+    __shared__ float part[32][33];
+    const int cols = 2 * J, cl = threadIdx.x & 31, grp = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
     float s = 0.f;
-    if (grp < groups)
-        for (int n = grp; n < N; n += groups) s += lnpart[(size_t)n * cols + c];
-    part[threadIdx.x] = s;
+    if (c < cols)
+#pragma unroll 4
+        for (int n = grp; n < N; n += 32) s += lnpart[(size_t)n * cols + c];
+    part[grp][cl] = s;
     __syncthreads();
-    if (grp != 0) return;
+    if (grp != 0 || c >= cols) return;
     float t = 0.f;
-    for (int r = 0; r < groups; ++r) t += part[r * cols + c];
+#pragma unroll
+    for (int r = 0; r < 32; ++r) t += part[r][cl];
     float* dst = (c < J ? dgamma : dbeta) + (c < J ? c : c - J);
     *dst = accumulate ? *dst + t : t;
 }
@@ -286,7 +288,7 @@ PHNET_API int phnet_dyn_bmm_ln_relu_bwd(const float* dy, const float* x, const f
     DYN_DISPATCH(K, J, CALL)
 #undef CALL
     if (rc != PHNET_OK) return rc;
-    hipLaunchKernelGGL(dyn_ln_grad_reduce_kernel, dim3(1), dim3(1024), 0, st, (const float*)workspace, dgamma, dbeta,
+    hipLaunchKernelGGL(dyn_ln_grad_reduce_kernel, dim3((2 * J + 31) / 32), dim3(1024), 0, st, (const float*)workspace, dgamma, dbeta,
                        N, J, param_accumulate);
     return phnet_launch_status();
 }
