@@ -377,13 +377,19 @@ __global__ __launch_bounds__(THREADS) void conv_wgrad_kernel(
             *reinterpret_cast<f32x4*>(Bs + buf * B_FLOATS + b_kk[i] * B_PITCH + b_col[i]) = b_reg[i];
     };
 
+    // unsplit + accumulate: start the accumulators from the old gradient (its HBM latency overlaps the first tile's loads;
+    // the epilogue is then a plain store instead of a read-modify-write)
+    const bool from_old = g.splits == 1 && accumulate;
     f32x16 acc[FM][FN];
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            for (int e = 0; e < 16; ++e) {
+                const int n = n0 + wn + j * 32 + frag_col(lane), m = m0 + wm + i * 32 + frag_row(lane, e);
+                acc[i][j][e] = (from_old && n < NC && m < g.Co) ? out[(size_t)m * NC + n] : 0.f;
+            }
 
     if (p_begin < p_end) {
         load_global(p_begin);
@@ -415,7 +421,7 @@ __global__ __launch_bounds__(THREADS) void conv_wgrad_kernel(
                 const int m = m0 + wm + i * 32 + frag_row(lane, e);
                 if (m < g.Co) {
                     float* q = dst + (size_t)m * NC + n;
-                    *q = (direct && accumulate) ? *q + acc[i][j][e] : acc[i][j][e];
+                    *q = acc[i][j][e];
                 }
             }
     }
@@ -478,6 +484,18 @@ __global__ __launch_bounds__(THREADS) void linear_wgrad_smallp_kernel(
         br[i] = *reinterpret_cast<const f32x4*>(X + (ok ? (size_t)p * Ci + n : 0));
         bm |= (unsigned)ok << i;
     }
+    // accumulate mode: the accumulators START from the old gradient values, fetched now so that their (cold, HBM) latency
+    // overlaps the staging instead of sitting in a read-modify-write epilogue
+    f32x16 acc[FM][FN];
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int n = n0 + wn + j * 32 + frag_col(lane), m = m0 + wm + i * 32 + frag_row(lane, e);
+                acc[i][j][e] = (accumulate && n < Ci && m < Co) ? dw[(size_t)m * Ci + n] : 0.f;
+            }
     const f32x4 zero{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i) {
@@ -491,13 +509,6 @@ __global__ __launch_bounds__(THREADS) void linear_wgrad_smallp_kernel(
     }
     __syncthreads();
 
-    f32x16 acc[FM][FN];
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     for (int ks = 0; ks < P16 / BK; ++ks) {
         float a[FM][8], b[FN][8];
         read_kstrided<FM, AP>(As + wm, lane, ks, a);
@@ -513,10 +524,7 @@ __global__ __launch_bounds__(THREADS) void linear_wgrad_smallp_kernel(
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int m = m0 + wm + i * 32 + frag_row(lane, e);
-                if (m < Co) {
-                    float* q = dw + (size_t)m * Ci + n;
-                    *q = accumulate ? *q + acc[i][j][e] : acc[i][j][e];
-                }
+                if (m < Co) dw[(size_t)m * Ci + n] = acc[i][j][e];
             }
     }
     if (want_bias && n0 == 0) {                                      // column sums of the staged dY tile: 4 row groups, then fold
