@@ -550,11 +550,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nw + nb) return;
     const long stride = nw + nb;
-    float s = part[i];
-    for (int z = 1; z < splits; ++z) s += part[i + (long)z * stride];
     float* dst = i < nw ? dw + i : dbias + (i - nw);
     if (i >= nw && !dbias) return;
-    *dst = accumulate ? *dst + s : s;
+    const float old = accumulate ? *dst : 0.f;           // cold read first: it overlaps the partial sums
+    float s = part[i];
+    for (int z = 1; z < splits; ++z) s += part[i + (long)z * stride];
+    *dst = old + s;
 }
 
 // ---- stem helpers: NCHW (3 ch) -> NHWC padded to 4 channels; OHWI weight pad 3->4 and back -----------

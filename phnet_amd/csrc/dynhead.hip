@@ -206,6 +206,8 @@ __global__ __launch_bounds__(1024) void dyn_ln_grad_reduce_kernel(const float* _
 {
     __shared__ float part[32][33];
     const int cols = 2 * J, cl = threadIdx.x & 31, grp = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
+    float* dst = (c < J ? dgamma : dbeta) + (c < J ? c : c - J);
+    const float old = (accumulate && grp == 0 && c < cols) ? *dst : 0.f;      // cold read first
     float s = 0.f;
     if (c < cols)
 #pragma unroll 4
@@ -216,8 +218,7 @@ __global__ __launch_bounds__(1024) void dyn_ln_grad_reduce_kernel(const float* _
     float t = 0.f;
 #pragma unroll
     for (int r = 0; r < 32; ++r) t += part[r][cl];
-    float* dst = (c < J ? dgamma : dbeta) + (c < J ? c : c - J);
-    *dst = accumulate ? *dst + t : t;
+    *dst = old + t;
 }
 
 template <int K, int J>

@@ -285,15 +285,16 @@ __global__ __launch_bounds__(256) void gate_ln_grad_reduce_kernel(const float* _
     const long col = (long)blockIdx.x * 256 + threadIdx.x;
     if (col >= 18L * CP) return;
     const int j = (int)(col / CP), i = (int)(col - (long)j * CP);
-    double s = 0.0;
-#pragma unroll 8
-    for (int n = 0; n < N; ++n) s += (double)lnpart[((size_t)n * 18 + j) * CP + i];
     // parameter slot of LayerNorm j: 0,1 -> ln0 (w,b); then block b: ln1 (w,b) at 2+8b+2, ln2 (w,b) at 2+8b+6
     int slot;
     if (j < 2) slot = j;
     else { const int b = (j - 2) / 4, r = (j - 2) % 4; slot = 2 + 8 * b + (r < 2 ? 2 + r : 6 + (r - 2)); }
     float* dst = dg.p[slot] + i;
-    *dst = accumulate ? *dst + (float)s : (float)s;
+    const float old = accumulate ? *dst : 0.f;           // cold read first: it overlaps the sum over the anchors
+    double s = 0.0;
+#pragma unroll 8
+    for (int n = 0; n < N; ++n) s += (double)lnpart[((size_t)n * 18 + j) * CP + i];
+    *dst = old + (float)s;
 }
 
 bool gate_args_ok(int N, int C, int P) { return N >= 1 && C >= 1 && P >= 1 && (long)C * P <= (long)NT * EPT; }

@@ -339,14 +339,15 @@ __global__ void layernorm_bwd_param_finalize_kernel(const float* __restrict__ pa
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= L) return;
+    const float old_w = accumulate ? dw[c] : 0.f, old_b = accumulate ? db[c] : 0.f;      // cold reads first: they overlap the sums
     double sw = 0.0, sb = 0.0;
 #pragma unroll 8
     for (int s = 0; s < slabs; ++s) {                 // independent loads: unrolled so that they are in flight together
         sw += (double)partial[((size_t)s * 2 + 0) * L + c];
         sb += (double)partial[((size_t)s * 2 + 1) * L + c];
     }
-    dw[c] = accumulate ? dw[c] + (float)sw : (float)sw;
-    db[c] = accumulate ? db[c] + (float)sb : (float)sb;
+    dw[c] = old_w + (float)sw;
+    db[c] = old_b + (float)sb;
 }
 
 // ---- depth-wise 3x3 over each anchor's (C x P) plane, zero padding 1 --------------------------------------

@@ -309,10 +309,11 @@ __global__ void colsum_finalize_kernel(const float* __restrict__ part, float* __
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
+    const float old = accumulate ? out[c] : 0.f;         // cold read first
     double t = 0.0;
 #pragma unroll 8
     for (int s = 0; s < slabs; ++s) t += (double)part[(size_t)s * C + c];
-    out[c] = accumulate ? out[c] + (float)t : (float)t;
+    out[c] = old + (float)t;
 }
 
 bool channels_ok(int C) { return C >= 4 && (C & 3) == 0 && (C >> 2) <= NT && NT % (C >> 2) == 0; }
