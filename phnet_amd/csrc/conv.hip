@@ -198,13 +198,24 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(
         }
     };
 
+    // unsplit launches start their accumulators from bias (+ addend): those reads overlap the first K tile's loads and the
+    // epilogue has no loads left (16 dependent global reads per fragment, each waited for, when the addend sat there)
+    const bool final_pass = g.splits == 1;
     f32x16 acc[FM][FN];
 #pragma unroll
-    for (int i = 0; i < FM; ++i)
+    for (int j = 0; j < FN; ++j) {
+        const int n = n0 + wn + j * 32 + frag_col(lane);
+        const bool nok = n < g.Co;
+        const float bv = (final_pass && bias && nok) ? bias[n] : 0.f;
 #pragma unroll
-        for (int j = 0; j < FN; ++j)
+        for (int i = 0; i < FM; ++i)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm + i * 32 + frag_row(lane, e);
+                const bool ok = final_pass && addend && nok && m < M;
+                acc[i][j][e] = bv + (ok ? addend[(size_t)(ok ? m : 0) * g.Co + (ok ? n : 0)] : 0.f);
+            }
+    }
 
     auto multiply_tile = [&](int buf, int kt) {
 #pragma unroll
@@ -235,23 +246,16 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(
 
     // ---- epilogue: bias / relu, or raw partial sums when split-K --------------------------------
     float* dst = out + (size_t)blockIdx.z * M * g.Co;
-    const bool final_pass = g.splits == 1;
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
         const int n = n0 + wn + j * 32 + frag_col(lane);
         if (n >= g.Co) continue;
-        const float bv = (final_pass && bias) ? bias[n] : 0.f;
 #pragma unroll
         for (int i = 0; i < FM; ++i)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int m = m0 + wm + i * 32 + frag_row(lane, e);
-                if (m < M) {
-                    float v = acc[i][j][e] + bv;
-                    if (final_pass && addend) v += addend[(size_t)m * g.Co + n];
-                    if (final_pass && relu) v = fmaxf(v, 0.f);
-                    dst[(size_t)m * g.Co + n] = v;
-                }
+                if (m < M) dst[(size_t)m * g.Co + n] = (final_pass && relu) ? fmaxf(acc[i][j][e], 0.f) : acc[i][j][e];
             }
     }
 }
