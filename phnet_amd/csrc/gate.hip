@@ -46,11 +46,18 @@ __device__ __forceinline__ void plane_stats(const float (&v)[EPT], int CP, float
 }
 
 // out[k] = bias + sum_taps f[tap] * plane(c+di-1, p+dj-1)   (zero padding); flip -> 180-degree rotated filter
+__device__ __forceinline__ void load_filter(const float* f9, bool flip, float (&f)[9]) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) f[t] = f9[flip ? 8 - t : t];
+}
+__device__ __forceinline__ void dwconv_apply(const float* plane, const float (&f)[9], float bias, int C, int P, int CP, float (&out)[EPT]);
 __device__ __forceinline__ void dwconv_plane(const float* plane, const float* f9, float bias, int C, int P, int CP, bool flip,
                                              float (&out)[EPT]) {
     float f[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) f[t] = f9[flip ? 8 - t : t];
+    load_filter(f9, flip, f);
+    dwconv_apply(plane, f, bias, C, P, CP, out);
+}
+__device__ __forceinline__ void dwconv_apply(const float* plane, const float (&f)[9], float bias, int C, int P, int CP, float (&out)[EPT]) {
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
         const int i = threadIdx.x + k * NT;
@@ -75,7 +82,11 @@ __device__ __forceinline__ void dwconv_plane(const float* plane, const float* f9
 
 __device__ __forceinline__ void load_plane(const float* src, int CP, float (&v)[EPT]) {
 #pragma unroll
-    for (int k = 0; k < EPT; ++k) { const int i = threadIdx.x + k * NT; v[k] = i < CP ? src[i] : 0.f; }
+    for (int k = 0; k < EPT; ++k) {                   // branch-free: the loads of several planes stay in flight together
+        const int i = threadIdx.x + k * NT;
+        const float t = src[i < CP ? i : 0];
+        v[k] = i < CP ? t : 0.f;
+    }
 }
 __device__ __forceinline__ void store_plane(float* dst, int CP, const float (&v)[EPT]) {
 #pragma unroll
@@ -178,7 +189,7 @@ __device__ __forceinline__ void filter_grad_partials(const float* src_plane, con
 
 // LayerNorm backward on register planes: g = upstream (already masked), xin = LN input; writes the affine partials
 // (g*xhat, g) to lnpart and returns dx in g.
-__device__ __forceinline__ void ln_backward(float (&g)[EPT], const float (&xin)[EPT], float mu, float rs, const float* gamma,
+__device__ __forceinline__ void ln_backward(float (&g)[EPT], const float (&xin)[EPT], float mu, float rs, const float (&gamma)[EPT],
                                             float* part_w, float* part_b, int CP, float* red) {
     float xh[EPT];
     float s1 = 0.f, s2 = 0.f;
@@ -190,7 +201,7 @@ __device__ __forceinline__ void ln_backward(float (&g)[EPT], const float (&xin)[
             xh[k] = (xin[k] - mu) * rs;
             part_w[i] = g[k] * xh[k];
             part_b[i] = g[k];
-            const float gw = g[k] * gamma[i];
+            const float gw = g[k] * gamma[k];
             g[k] = gw;
             s1 += gw;
             s2 += gw * xh[k];
@@ -216,30 +227,35 @@ __global__ __launch_bounds__(NT) void gate_stack_bwd_kernel(const float* __restr
     float* P1 = lds + CP;
     const size_t plane_off = (size_t)n * CP, slab = (size_t)N * CP;
     float* lp = lnpart + (size_t)n * 18 * CP;
-    float g[EPT], a[EPT], v[EPT], acc[10];
+    float g[EPT], v[EPT], acc[10];
     load_plane(gout + plane_off, CP, g);
     for (int b = 3; b >= 0; --b) {
         const float* const* q = w.p + 2 + 8 * b;
         float* const* dq = dg.p + 2 + 8 * b;
+        // every global read of this block is issued up front (saved planes, LayerNorm affine, statistics): one exposed
+        // memory latency per block instead of one per phase - the kernel is a chain of latencies, not of FLOPs
+        float a_o[EPT], a_t[EPT], a[EPT], a_s[EPT], ln2w[EPT], ln1w[EPT], ln1b[EPT];
+        load_plane(b == 3 ? out + plane_off : planes + (size_t)(b + 1) * slab + plane_off, CP, a_o);     // block output
+        load_plane(planes + (size_t)(8 + b) * slab + plane_off, CP, a_t);                                // t_b
+        load_plane(planes + (size_t)(4 + b) * slab + plane_off, CP, a);                                  // u_b
+        load_plane(planes + (size_t)b * slab + plane_off, CP, a_s);                                      // s_b
+        load_plane(q[6], CP, ln2w);
+        load_plane(q[2], CP, ln1w);
+        load_plane(q[3], CP, ln1b);
+        const float mu2 = stats[n * 18 + 4 + 4 * b], rs2 = stats[n * 18 + 5 + 4 * b];
+        const float mu1 = stats[n * 18 + 2 + 4 * b], rs1 = stats[n * 18 + 3 + 4 * b];
         // ---- relu of the block output, then LN2 backward (input t_b) ----
-        load_plane(b == 3 ? out + plane_off : planes + (size_t)(b + 1) * slab + plane_off, CP, a);
 #pragma unroll
-        for (int k = 0; k < EPT; ++k) g[k] = a[k] > 0.f ? g[k] : 0.f;
+        for (int k = 0; k < EPT; ++k) g[k] = a_o[k] > 0.f ? g[k] : 0.f;
         float gres[EPT];
 #pragma unroll
         for (int k = 0; k < EPT; ++k) gres[k] = g[k];
-        load_plane(planes + (size_t)(8 + b) * slab + plane_off, CP, a);                        // t_b
-        ln_backward(g, a, stats[n * 18 + 4 + 4 * b], stats[n * 18 + 5 + 4 * b], q[6], lp + (size_t)(2 + 4 * b + 2) * CP,
-                    lp + (size_t)(2 + 4 * b + 3) * CP, CP, red);                               // g = dt
+        ln_backward(g, a_t, mu2, rs2, ln2w, lp + (size_t)(2 + 4 * b + 2) * CP, lp + (size_t)(2 + 4 * b + 3) * CP, CP, red);   // g = dt
         // ---- conv2 backward: needs v_b = relu(LN1(u_b)) and dt as planes ----
-        load_plane(planes + (size_t)(4 + b) * slab + plane_off, CP, a);                        // u_b
-        {
-            const float mu = stats[n * 18 + 2 + 4 * b], rs = stats[n * 18 + 3 + 4 * b];
 #pragma unroll
-            for (int k = 0; k < EPT; ++k) {
-                const int i = threadIdx.x + k * NT;
-                v[k] = i < CP ? fmaxf((a[k] - mu) * rs * q[2][i] + q[3][i], 0.f) : 0.f;
-            }
+        for (int k = 0; k < EPT; ++k) {
+            const int i = threadIdx.x + k * NT;
+            v[k] = i < CP ? fmaxf((a[k] - mu1) * rs1 * ln1w[k] + ln1b[k], 0.f) : 0.f;
         }
         __syncthreads();
         store_plane(P0, CP, v);
@@ -252,12 +268,10 @@ __global__ __launch_bounds__(NT) void gate_stack_bwd_kernel(const float* __restr
 #pragma unroll
         for (int k = 0; k < EPT; ++k) g[k] = v[k] > 0.f ? dv[k] : 0.f;                         // through the inner relu
         // ---- LN1 backward (input u_b, still in a[]) ----
-        ln_backward(g, a, stats[n * 18 + 2 + 4 * b], stats[n * 18 + 3 + 4 * b], q[2], lp + (size_t)(2 + 4 * b + 0) * CP,
-                    lp + (size_t)(2 + 4 * b + 1) * CP, CP, red);                               // g = du
+        ln_backward(g, a, mu1, rs1, ln1w, lp + (size_t)(2 + 4 * b + 0) * CP, lp + (size_t)(2 + 4 * b + 1) * CP, CP, red);     // g = du
         // ---- conv1 backward: input s_b ----
-        load_plane(planes + (size_t)b * slab + plane_off, CP, a);                              // s_b
         __syncthreads();
-        store_plane(P0, CP, a);
+        store_plane(P0, CP, a_s);
         store_plane(P1, CP, g);
         __syncthreads();
         filter_grad_partials(P0, g, C, P, CP, acc);
@@ -267,6 +281,7 @@ __global__ __launch_bounds__(NT) void gate_stack_bwd_kernel(const float* __restr
         for (int k = 0; k < EPT; ++k) g[k] = dv[k] + gres[k];                                  // + residual path
     }
     // ---- pre-norm: only its affine gradients are needed (the gate input is detached, Router4OL.py:275) ----
+    float a[EPT];
     load_plane(x + plane_off, CP, a);
     {
         const float mu = stats[n * 18 + 0], rs = stats[n * 18 + 1];
