@@ -47,6 +47,10 @@ def lib():
             raise RuntimeError(
                 f"{SO_PATH} is missing: the HIP extension has not been built (python -m phnet_amd.build). "
                 "phnet_amd has no CPU / eager fallback.")
+        # PyTorch ships its own copy of the HIP runtime: it must be in the process BEFORE this library is loaded, so that the
+        # loader binds libphnet_hip.so to that same runtime (two runtimes = our kernels registered with one, torch's streams
+        # and device pointers owned by the other: every launch fails)
+        import torch  # noqa: F401
         handle = ctypes.CDLL(SO_PATH)
         for name, restype, argtypes in declared_functions():
             fn = getattr(handle, name)          # AttributeError if the .so lacks a declared symbol
