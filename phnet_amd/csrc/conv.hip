@@ -238,6 +238,10 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(
         for (int t = 0; t < ntiles; ++t) {
             load_global(k_begin + (t + 1) * BKT, a_set0, b_set0, mask0);      // past the end: fully masked
             multiply_tile(buf, k_begin + t * BKT);
+            // keep the LDS fill (and the wait for the global loads in front of it) BEHIND the MFMAs: left alone, the
+            // scheduler hoists it above them - the operands are already in registers - and every wave then sits out its
+            // full load latency before it issues a single MFMA
+            __builtin_amdgcn_sched_barrier(0);
             store_lds(buf ^ 1, a_set0, b_set0, mask0);
             __syncthreads();
             buf ^= 1;
@@ -350,35 +354,48 @@ __global__ __launch_bounds__(THREADS) void conv_wgrad_kernel(
     for (int i = 0; i < A_LOADS; ++i) bsum[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const bool bias_block = want_bias && n0 == 0;            // the first column tile also sums dY over the pixels
     // loads the K step that starts at pixel pt; MUST be called with pt = p_begin, p_begin+BK, ... in order
-    auto load_global = [&](int pt) {
+    // branch-free loads (masked chunks read element 0 and are zeroed on the LDS write): straight-line code, exact s_waitcnt
+    unsigned lmask = 0;
+    auto load_global = [&](int pt, bool advance) {
+        lmask = 0;
+        if (advance) {                                   // pixel carry of the B gather: BEFORE the loads, so that nothing but
+#pragma unroll                                           // straight-line code sits between them and the MFMAs
+            for (int i = 0; i < B_LOADS; ++i) {
+                b_ox[i] += BK;
+                while (b_ox[i] >= g.Wo) {
+                    b_ox[i] -= g.Wo;
+                    if (++b_oy[i] == g.Ho) { b_oy[i] = 0; ++b_n[i]; }
+                }
+            }
+        }
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i) {
             const int p = pt + a_kk[i], co = m0 + a_ch[i];
-            a_reg[i] = (p < p_end && co < g.Co) ? *reinterpret_cast<const f32x4*>(dY + (size_t)p * g.Co + co)
-                                                : f32x4{0.f, 0.f, 0.f, 0.f};
-            if (bias_block) bsum[i] += a_reg[i];
+            const bool ok = p < p_end && co < g.Co;
+            a_reg[i] = *reinterpret_cast<const f32x4*>(dY + (ok ? (size_t)p * g.Co + co : 0));
+            lmask |= (unsigned)ok << i;
         }
 #pragma unroll
         for (int i = 0; i < B_LOADS; ++i) {
             const int p = pt + b_kk[i];
             const int iy = b_oy[i] * g.stride - g.pad + b_r[i], ix = b_ox[i] * g.stride - g.pad + b_q[i];
             const bool ok = b_ok[i] && p < p_end && iy >= 0 && iy < g.Hi && ix >= 0 && ix < g.Wi;
-            b_reg[i] = ok ? *reinterpret_cast<const f32x4*>(X + ((size_t)(b_n[i] * g.Hi + iy) * g.Wi + ix) * g.Ci + b_c[i])
-                          : f32x4{0.f, 0.f, 0.f, 0.f};
-            b_ox[i] += BK;
-            while (b_ox[i] >= g.Wo) {
-                b_ox[i] -= g.Wo;
-                if (++b_oy[i] == g.Ho) { b_oy[i] = 0; ++b_n[i]; }
-            }
+            const int pix = ok ? (b_n[i] * g.Hi + iy) * g.Wi + ix : 0;
+            b_reg[i] = *reinterpret_cast<const f32x4*>(X + (size_t)pix * g.Ci + (ok ? b_c[i] : 0));
+            lmask |= (unsigned)ok << (16 + i);
         }
     };
     auto store_lds = [&](int buf) {
+        const f32x4 zero{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < A_LOADS; ++i)
-            *reinterpret_cast<f32x4*>(As + buf * A_FLOATS + a_kk[i] * A_PITCH + a_ch[i]) = a_reg[i];
+        for (int i = 0; i < A_LOADS; ++i) {
+            const f32x4 v = (lmask >> i) & 1u ? a_reg[i] : zero;
+            if (bias_block) bsum[i] += v;
+            *reinterpret_cast<f32x4*>(As + buf * A_FLOATS + a_kk[i] * A_PITCH + a_ch[i]) = v;
+        }
 #pragma unroll
         for (int i = 0; i < B_LOADS; ++i)
-            *reinterpret_cast<f32x4*>(Bs + buf * B_FLOATS + b_kk[i] * B_PITCH + b_col[i]) = b_reg[i];
+            *reinterpret_cast<f32x4*>(Bs + buf * B_FLOATS + b_kk[i] * B_PITCH + b_col[i]) = (lmask >> (16 + i)) & 1u ? b_reg[i] : zero;
     };
 
     // unsplit + accumulate: start the accumulators from the old gradient (its HBM latency overlaps the first tile's loads;
@@ -392,22 +409,24 @@ __global__ __launch_bounds__(THREADS) void conv_wgrad_kernel(
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int n = n0 + wn + j * 32 + frag_col(lane), m = m0 + wm + i * 32 + frag_row(lane, e);
-                acc[i][j][e] = (from_old && n < NC && m < g.Co) ? out[(size_t)m * NC + n] : 0.f;
+                const bool ok = from_old && n < NC && m < g.Co;
+                const float v = out[ok ? (size_t)m * NC + n : 0];                 // branch-free: all 16 reads in flight together
+                acc[i][j][e] = ok ? v : 0.f;
             }
 
     if (p_begin < p_end) {
-        load_global(p_begin);
+        load_global(p_begin, false);
         store_lds(0);
         __syncthreads();
         int buf = 0;
         for (int pt = p_begin; pt < p_end; pt += BK) {
-            const bool more = pt + BK < p_end;
-            if (more) load_global(pt + BK);
+            load_global(pt + BK, true);                  // past the end: fully masked
             float a[FM][8], b[FN][8];
             read_kstrided<FM, A_PITCH>(As + buf * A_FLOATS + wm, lane, 0, a);
             read_kstrided<FN, B_PITCH>(Bs + buf * B_FLOATS + wn, lane, 0, b);
             mma_step<FM, FN>(a, b, acc);
-            if (more) store_lds(buf ^ 1);
+            __builtin_amdgcn_sched_barrier(0);           // the LDS fill (and its wait for the loads) stays behind the MFMAs
+            store_lds(buf ^ 1);
             __syncthreads();
             buf ^= 1;
         }
