@@ -88,6 +88,13 @@ uint64_t phnet_conv2d_wgrad_workspace(int32_t N, int32_t Hi, int32_t Wi, int32_t
 int phnet_conv2d_wgrad(const float* dy, const float* x, float* dw, float* dbias,
                        int32_t N, int32_t Hi, int32_t Wi, int32_t Ci, int32_t Co, int32_t R, int32_t S,
                        int32_t stride, int32_t pad, int32_t accumulate, void* workspace, uint64_t ws_bytes, void* stream);
+/* Backward of a Linear layer over few rows (the M = 240 layers of the lane head) as ONE launch: dx [M][K] = dy w and
+ * dw [N][K] (+)= dy^T x, dbias [N] (+)= column sums of dy (dbias optional).  dy [M][N], x [M][K], w [N][K] row-major.
+ * phnet_linear_bwd_fusable tells whether a shape qualifies (M <= 256, N <= 512, few tiles); otherwise use
+ * phnet_conv2d_dgrad + phnet_conv2d_wgrad. */
+int phnet_linear_bwd_fusable(int64_t M, int64_t K, int64_t N);
+int phnet_linear_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, float* dbias,
+                     int32_t M, int32_t K, int32_t N, int32_t accumulate, void* stream);
 /* stem helpers: NCHW 3-channel frames -> NHWC padded to 4 channels; innermost-dimension pad/truncate. */
 int phnet_nchw3_to_nhwc4(const float* x, float* y, int32_t N, int32_t H, int32_t W, void* stream);
 int phnet_pad_channels(const float* src, float* dst, int64_t rows, int32_t cs, int32_t cd, void* stream);

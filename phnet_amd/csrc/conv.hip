@@ -34,10 +34,13 @@ struct ConvShape {
 
 struct RowCoord { int base, iy0, ix0; bool ok; };
 
+// The tile program is a device function so that one launch can run tiles of different GEMMs (linear_bwd_fused_kernel);
+// (block, nblocks, split) are what blockIdx.x / gridDim.x / blockIdx.z are for the plain kernel below.
 template <int BM, int BN, bool B_DGRAD, int BKT, bool UNI>
-__global__ __launch_bounds__(THREADS) void conv_igemm_kernel(
+__device__ __forceinline__ void igemm_tile(
     const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ bias,
-    const float* __restrict__ addend, float* __restrict__ out, ConvShape g, int relu)
+    const float* __restrict__ addend, float* __restrict__ out, const ConvShape& g, int relu,
+    float* lds, unsigned block, unsigned nblocks, unsigned split)
 {
     constexpr int TM = BM / 2, TN = BN / 2, FM = TM / 32, FN = TN / 32;
     constexpr int A_PITCH = KContigTile<BM, BKT>::PITCH;
@@ -48,16 +51,15 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(
     constexpr int ROWS_PER_PASS = THREADS / CHUNKS;         // 64 (BKT 16) or 16 (BKT 64)
     constexpr int A_LOADS = BM / ROWS_PER_PASS;             // float4 loads per thread per K tile
     constexpr int B_LOADS = B_DGRAD ? (BKT * BN / 4) / THREADS : BN / ROWS_PER_PASS;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
     float* As = lds;
     float* Bs = lds + 2 * A_FLOATS;
 
     const int M = g.N * g.Ho * g.Wo;
     const int K = g.R * g.S * g.Ci;
     const int tiles_n = (g.Co + BN - 1) / BN;
-    const unsigned tile = xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned tile = xcd_remap(block, nblocks);
     const int m0 = (int)(tile / tiles_n) * BM, n0 = (int)(tile % tiles_n) * BN;
-    const int k_begin = blockIdx.z * g.k_per_split;
+    const int k_begin = split * g.k_per_split;
     const int k_end = min(K, k_begin + g.k_per_split);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave >> 1) * TM, wn = (wave & 1) * TN;
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(
     }
 
     // ---- epilogue: bias / relu, or raw partial sums when split-K --------------------------------
-    float* dst = out + (size_t)blockIdx.z * M * g.Co;
+    float* dst = out + (size_t)split * M * g.Co;
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
         const int n = n0 + wn + j * 32 + frag_col(lane);
@@ -262,6 +264,15 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(
                 if (m < M) dst[(size_t)m * g.Co + n] = (final_pass && relu) ? fmaxf(acc[i][j][e], 0.f) : acc[i][j][e];
             }
     }
+}
+
+template <int BM, int BN, bool B_DGRAD, int BKT, bool UNI>
+__global__ __launch_bounds__(THREADS) void conv_igemm_kernel(
+    const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ bias,
+    const float* __restrict__ addend, float* __restrict__ out, ConvShape g, int relu)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    igemm_tile<BM, BN, B_DGRAD, BKT, UNI>(X, W, bias, addend, out, g, relu, lds, blockIdx.x, gridDim.x, blockIdx.z);
 }
 
 // out[i] = sum_z part[z][i] (+bias[i % ncols]) (relu)
@@ -473,20 +484,19 @@ __global__ __launch_bounds__(THREADS) void conv_wgrad_kernel(
 // dY tile.
 constexpr int SMALLP_MAX = 256;
 template <int BM, int BN>
-__global__ __launch_bounds__(THREADS) void linear_wgrad_smallp_kernel(
+__device__ __forceinline__ void smallp_tile(
     const float* __restrict__ dY, const float* __restrict__ X, float* __restrict__ dw, float* __restrict__ dbias,
-    int P, int Co, int Ci, int want_bias, int accumulate)
+    int P, int Co, int Ci, int want_bias, int accumulate, float* lds, unsigned block, unsigned nblocks)
 {
     constexpr int TM = BM / 2, TN = BN / 2, FM = TM / 32, FN = TN / 32;
     constexpr int AP = BM + 4, BP = BN + 4;
     constexpr int A_CH = BM / 4, B_CH = BN / 4;                     // float4 chunks per staged row
     constexpr int A_LOADS = SMALLP_MAX * A_CH / THREADS, B_LOADS = SMALLP_MAX * B_CH / THREADS;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
     const int P16 = (P + 15) & ~15;
     float* As = lds;
     float* Bs = lds + P16 * AP;
     const int tiles_n = (Ci + BN - 1) / BN;
-    const unsigned tile = xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned tile = xcd_remap(block, nblocks);
     const int m0 = (int)(tile / tiles_n) * BM, n0 = (int)(tile % tiles_n) * BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave >> 1) * TM, wn = (wave & 1) * TN;
@@ -564,6 +574,32 @@ __global__ __launch_bounds__(THREADS) void linear_wgrad_smallp_kernel(
             dbias[m0 + tid] = accumulate ? dbias[m0 + tid] + v : v;
         }
     }
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(THREADS) void linear_wgrad_smallp_kernel(
+    const float* __restrict__ dY, const float* __restrict__ X, float* __restrict__ dw, float* __restrict__ dbias,
+    int P, int Co, int Ci, int want_bias, int accumulate)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    smallp_tile<BM, BN>(dY, X, dw, dbias, P, Co, Ci, want_bias, accumulate, lds, blockIdx.x, gridDim.x);
+}
+
+// Backward of a Linear layer over few rows in ONE launch: the first `dgrad_tiles` workgroups compute the data gradient
+// dX = dY W (tiles of the implicit-GEMM program, K tile 64, unsplit), the others the weight (and bias) gradient with the
+// few-rows program above.  The two are independent - both only read dY - and each occupies a handful of CUs, so sharing a
+// launch removes one ~8 us dependent launch per layer (there are ~270 such layers in a step).
+template <bool UNI>
+__global__ __launch_bounds__(THREADS) void linear_bwd_fused_kernel(
+    const float* __restrict__ dY, const float* __restrict__ W, const float* __restrict__ X,
+    float* __restrict__ dX, float* __restrict__ dw, float* __restrict__ dbias,
+    ConvShape gd, unsigned dgrad_tiles, int P, int Co, int Ci, int want_bias, int accumulate)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    if (blockIdx.x < dgrad_tiles)
+        igemm_tile<64, 64, true, 64, UNI>(dY, W, nullptr, nullptr, dX, gd, 0, lds, blockIdx.x, dgrad_tiles, 0);
+    else
+        smallp_tile<64, 64>(dY, X, dw, dbias, P, Co, Ci, want_bias, accumulate, lds, blockIdx.x - dgrad_tiles, gridDim.x - dgrad_tiles);
 }
 
 // dW (+)= sum_z part[z][0:nw],  dbias (+)= sum_z part[z][nw:nw+nb]   (part rows are nw+nb floats long)
@@ -881,5 +917,52 @@ PHNET_API int phnet_pad_channels(const float* src, float* dst, int64_t rows, int
     if (!src || !dst) return PHNET_ERR_ARG;
     hipLaunchKernelGGL(pad_channels_kernel, dim3((unsigned)ceil_div64(rows * cd, 256)), dim3(256), 0, (hipStream_t)stream,
                        src, dst, (long)rows, cs, cd);
+    return phnet_launch_status();
+}
+
+// ---- fused backward of a Linear layer over few rows ------------------------------------------------------------------
+static bool linear_bwd_fusable(long M, long K, long N)
+{
+    if (!g_wgrad_smallp || M < 1 || M > SMALLP_MAX || (K & 3) || (N & 3) || K < 4 || N < 4) return false;
+    const long wt = ceil_div64(N, 64) * ceil_div64(K, 64), dt = ceil_div64(M, 64) * ceil_div64(K, 64);
+    return wt < g_smallp_max_tiles && N <= 512 && dt <= 256;          // dgrad stays unsplit: reduction length N <= 512
+}
+
+// 1 when phnet_linear_bwd runs (M, K, N) as ONE launch; 0: use phnet_conv2d_dgrad + phnet_conv2d_wgrad instead.
+PHNET_API int phnet_linear_bwd_fusable(int64_t M, int64_t K, int64_t N) { return linear_bwd_fusable(M, K, N) ? 1 : 0; }
+
+// Backward of y = x w^T (+ b) for few rows, one launch: dx [M][K] = dy w;  dw [N][K] and dbias [N] (optional) = dy^T x,
+// column sums of dy - overwritten or, with accumulate = 1, added to.  dy [M][N], x [M][K], w [N][K], all row-major.
+// Only for shapes with phnet_linear_bwd_fusable(M, K, N) == 1 (PHNET_ERR_ARG otherwise).
+PHNET_API int phnet_linear_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, float* dbias,
+                               int32_t M, int32_t K, int32_t N, int32_t accumulate, void* stream)
+{
+    if (!linear_bwd_fusable(M, K, N) || !dy || !x || !w || !dx || !dw) return PHNET_ERR_ARG;
+    ConvShape g{};
+    g.N = M; g.Hi = 1; g.Wi = 1; g.Ci = N;              // A side = dY rows, N channels
+    g.Ho = 1; g.Wo = 1; g.Co = K;                       // output = dX
+    g.R = 1; g.S = 1; g.stride = 1; g.pad = 0; g.in_dil = 1;
+    g.splits = 1;
+    g.k_per_split = (int)(ceil_div64(N, 64) * 64);
+    const unsigned dt = (unsigned)(ceil_div64(M, 64) * ceil_div64(K, 64)), wt = (unsigned)(ceil_div64(N, 64) * ceil_div64(K, 64));
+    const int P16 = (M + 15) & ~15;
+    const size_t lds_dgrad = 2 * (size_t)(KContigTile<64, 64>::FLOATS + KStridedTile<64, 64>::FLOATS) * sizeof(float);
+    const size_t lds_wgrad = (size_t)P16 * 68 * 2 * sizeof(float);
+    const size_t lds = lds_dgrad > lds_wgrad ? lds_dgrad : lds_wgrad;
+    static bool attr = false;
+    if (!attr) {
+        const int cap = (int)((size_t)SMALLP_MAX * 68 * 2 * sizeof(float));
+        if (hipFuncSetAttribute((const void*)linear_bwd_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
+            hipFuncSetAttribute((const void*)linear_bwd_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess)
+            return PHNET_ERR_LAUNCH;
+        attr = true;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (N % 64 == 0 && g_uniform_tap)
+        hipLaunchKernelGGL((linear_bwd_fused_kernel<true>), dim3(dt + wt), dim3(THREADS), lds, st, dy, w, x, dx, dw, dbias, g, dt,
+                           (int)M, (int)N, (int)K, dbias != nullptr, accumulate);
+    else
+        hipLaunchKernelGGL((linear_bwd_fused_kernel<false>), dim3(dt + wt), dim3(THREADS), lds, st, dy, w, x, dx, dw, dbias, g, dt,
+                           (int)M, (int)N, (int)K, dbias != nullptr, accumulate);
     return phnet_launch_status();
 }

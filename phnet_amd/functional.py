@@ -48,9 +48,14 @@ class _Linear(torch.autograd.Function):
         g = g.contiguous()
         if ctx.relu:
             g = K.relu_bwd(g, y)
+        want_b = ctx.has_b and ctx.needs_input_grad[2]
+        if (ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and ctx.w_direct is not None and
+                (not want_b or ctx.b_direct is not None) and K.linear_bwd_fusable(g.shape[0], x2.shape[1], n4)):
+            # few-rows layer with arena / sink destinations: data, weight and bias gradient from ONE launch
+            dx = K.linear_bwd(g, x2, w, ctx.w_direct, ctx.b_direct if want_b else None, accumulate=True)
+            return dx.view(ctx.xshape), None, None, None, None
         dx = K.linear_dgrad(g, w).view(ctx.xshape) if ctx.needs_input_grad[0] else None
         dw = db = None
-        want_b = ctx.has_b and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             # weight and bias gradient come out of the same launch (the bias gradient is the column sum of g)
             if ctx.w_direct is not None and (not want_b or ctx.b_direct is not None):

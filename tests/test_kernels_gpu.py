@@ -506,6 +506,27 @@ def test_dropout_add_layernorm_fused(ops, L):
     close(dx2[kept], (dres2 / (1 - p))[kept], 1e-5)
 
 
+@pytest.mark.parametrize("M,K,N", [(240, 128, 384), (240, 192, 44), (240, 256, 128), (37, 64, 64), (256, 2304, 64)])
+def test_linear_backward_fused_launch(ops, M, K, N):
+    """dx, dW (accumulated) and dbias of a few-rows Linear layer from ONE launch vs fp64 torch."""
+    assert ops.linear_bwd_fusable(M, K, N)
+    assert not ops.linear_bwd_fusable(300, K, N) and not ops.linear_bwd_fusable(M, K, 1024)
+    torch.manual_seed(M + K + N)
+    x = torch.randn(M, K, dtype=torch.float64)
+    w = torch.randn(N, K, dtype=torch.float64) / K ** 0.5
+    dy = torch.randn(M, N, dtype=torch.float64)
+    dw0, db0 = torch.randn(N, K, dtype=torch.float64), torch.randn(N, dtype=torch.float64)
+    dwd, dbd = dev(dw0.float()), dev(db0.float())
+    dx = ops.linear_bwd(dev(dy.float()), dev(x.float()), dev(w.float()), dwd, dbd, accumulate=True)
+    close(dx, dy @ w, 3e-5)
+    close(dwd, dw0 + dy.t() @ x, 3e-5)
+    close(dbd, db0 + dy.sum(0), 3e-5)
+    dw1 = torch.empty_like(dwd)
+    dx1 = ops.linear_bwd(dev(dy.float()), dev(x.float()), dev(w.float()), dw1, None, accumulate=False)
+    assert torch.equal(dx1, dx)
+    close(dw1, dy.t() @ x, 3e-5)
+
+
 def test_memory_tokens_gate_tail_blend(ops):
     """The three small fused pieces of the per-frame loop against their tensor-op definitions."""
     torch.manual_seed(21)
