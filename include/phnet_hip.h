@@ -93,8 +93,9 @@ int phnet_conv2d_wgrad(const float* dy, const float* x, float* dw, float* dbias,
  * phnet_linear_bwd_fusable tells whether a shape qualifies (M <= 256, N <= 512, few tiles); otherwise use
  * phnet_conv2d_dgrad + phnet_conv2d_wgrad. */
 int phnet_linear_bwd_fusable(int64_t M, int64_t K, int64_t N);
-int phnet_linear_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, float* dbias,
-                     int32_t M, int32_t K, int32_t N, int32_t accumulate, void* stream);
+int phnet_linear_bwd(const float* dy, const float* x, const float* w, const float* relu_y, float* dx, float* dw, float* dbias,
+                     int32_t M, int32_t K, int32_t N, int32_t accumulate, void* stream);   /* relu_y (optional, [M][N]): saved
+                     output of a layer that ended in a ReLU; dy is masked by relu_y > 0 while it is staged */
 /* stem helpers: NCHW 3-channel frames -> NHWC padded to 4 channels; innermost-dimension pad/truncate. */
 int phnet_nchw3_to_nhwc4(const float* x, float* y, int32_t N, int32_t H, int32_t W, void* stream);
 int phnet_pad_channels(const float* src, float* dst, int64_t rows, int32_t cs, int32_t cd, void* stream);

@@ -36,11 +36,13 @@ struct RowCoord { int base, iy0, ix0; bool ok; };
 
 // The tile program is a device function so that one launch can run tiles of different GEMMs (linear_bwd_fused_kernel);
 // (block, nblocks, split) are what blockIdx.x / gridDim.x / blockIdx.z are for the plain kernel below.
-template <int BM, int BN, bool B_DGRAD, int BKT, bool UNI>
+// AMASK: the A operand is a gradient that still has to pass a ReLU - element (row, k) counts only where amask (the saved
+// forward output of that ReLU, same layout as X) is positive; applied when the tile is written to LDS.
+template <int BM, int BN, bool B_DGRAD, int BKT, bool UNI, bool AMASK = false>
 __device__ __forceinline__ void igemm_tile(
     const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ bias,
     const float* __restrict__ addend, float* __restrict__ out, const ConvShape& g, int relu,
-    float* lds, unsigned block, unsigned nblocks, unsigned split)
+    float* lds, unsigned block, unsigned nblocks, unsigned split, const float* __restrict__ amask = nullptr)
 {
     constexpr int TM = BM / 2, TN = BN / 2, FM = TM / 32, FN = TN / 32;
     constexpr int A_PITCH = KContigTile<BM, BKT>::PITCH;
@@ -128,6 +130,7 @@ __device__ __forceinline__ void igemm_tile(
     // code the compiler can schedule and count (s_waitcnt) exactly.  (A second register set prefetching two tiles ahead
     // was measured too: +4 % on the trunk forward, -3 % on the skinny head GEMMs, no gain on the step - not kept.)
     f32x4 a_set0[A_LOADS], b_set0[B_LOADS];
+    f32x4 a_relu[AMASK ? A_LOADS : 1];
     unsigned mask0 = 0;
     // loads the K tile that starts at kt; MUST be called with kt = k_begin, k_begin+BKT, ... in order
     auto load_global = [&](int kt, f32x4 (&a_reg)[A_LOADS], f32x4 (&b_reg)[B_LOADS], unsigned& mask) {
@@ -147,6 +150,7 @@ __device__ __forceinline__ void igemm_tile(
             ok = ok && ty < g.Hi && tx < g.Wi;
             const int pix = ok ? rc[i].base + ty * g.Wi + tx : 0;         // masked: pixel 0 (valid memory, value discarded)
             a_reg[i] = *reinterpret_cast<const f32x4*>(X + (size_t)pix * g.Ci + (kok ? tap_c : 0));
+            if (AMASK) a_relu[i] = *reinterpret_cast<const f32x4*>(amask + (size_t)pix * g.Ci + (kok ? tap_c : 0));
             mask |= (unsigned)ok << i;
         }
         if (!uni) kpos_advance(ka, g.Ci);
@@ -186,8 +190,14 @@ __device__ __forceinline__ void igemm_tile(
         float* b = Bs + buf * B_FLOATS;
         const f32x4 zero{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < A_LOADS; ++i)
-            *reinterpret_cast<f32x4*>(a + (a_row + ROWS_PER_PASS * i) * A_PITCH + a_chunk * 4) = (mask >> i) & 1u ? a_reg[i] : zero;
+        for (int i = 0; i < A_LOADS; ++i) {
+            f32x4 v = (mask >> i) & 1u ? a_reg[i] : zero;
+            if (AMASK) {
+                v.x = a_relu[i].x > 0.f ? v.x : 0.f; v.y = a_relu[i].y > 0.f ? v.y : 0.f;
+                v.z = a_relu[i].z > 0.f ? v.z : 0.f; v.w = a_relu[i].w > 0.f ? v.w : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(a + (a_row + ROWS_PER_PASS * i) * A_PITCH + a_chunk * 4) = v;
+        }
         if (!B_DGRAD) {
 #pragma unroll
             for (int i = 0; i < B_LOADS; ++i)
@@ -483,10 +493,11 @@ __global__ __launch_bounds__(THREADS) void conv_wgrad_kernel(
 // the result goes (or accumulates) straight into the gradient arena.  The bias gradient is the column sum of the staged
 // dY tile.
 constexpr int SMALLP_MAX = 256;
-template <int BM, int BN>
+template <int BM, int BN, bool AMASK = false>
 __device__ __forceinline__ void smallp_tile(
     const float* __restrict__ dY, const float* __restrict__ X, float* __restrict__ dw, float* __restrict__ dbias,
-    int P, int Co, int Ci, int want_bias, int accumulate, float* lds, unsigned block, unsigned nblocks)
+    int P, int Co, int Ci, int want_bias, int accumulate, float* lds, unsigned block, unsigned nblocks,
+    const float* __restrict__ ymask = nullptr)
 {
     constexpr int TM = BM / 2, TN = BN / 2, FM = TM / 32, FN = TN / 32;
     constexpr int AP = BM + 4, BP = BN + 4;
@@ -501,13 +512,14 @@ __device__ __forceinline__ void smallp_tile(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave >> 1) * TM, wn = (wave & 1) * TN;
 
-    f32x4 ar[A_LOADS], br[B_LOADS];
+    f32x4 ar[A_LOADS], br[B_LOADS], ay[AMASK ? A_LOADS : 1];
     unsigned am = 0, bm = 0;
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i) {                            // branch-free: masked chunks read element 0
         const int idx = tid + THREADS * i, p = idx / A_CH, m = m0 + (idx - p * A_CH) * 4;
         const bool ok = p < P && m < Co;
         ar[i] = *reinterpret_cast<const f32x4*>(dY + (ok ? (size_t)p * Co + m : 0));
+        if (AMASK) ay[i] = *reinterpret_cast<const f32x4*>(ymask + (ok ? (size_t)p * Co + m : 0));
         am |= (unsigned)ok << i;
     }
 #pragma unroll
@@ -533,7 +545,12 @@ __device__ __forceinline__ void smallp_tile(
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i) {
         const int idx = tid + THREADS * i, p = idx / A_CH;
-        if (p < P16) *reinterpret_cast<f32x4*>(As + p * AP + (idx - p * A_CH) * 4) = (am >> i) & 1u ? ar[i] : zero;
+        f32x4 v = (am >> i) & 1u ? ar[i] : zero;
+        if (AMASK) {
+            v.x = ay[i].x > 0.f ? v.x : 0.f; v.y = ay[i].y > 0.f ? v.y : 0.f;
+            v.z = ay[i].z > 0.f ? v.z : 0.f; v.w = ay[i].w > 0.f ? v.w : 0.f;
+        }
+        if (p < P16) *reinterpret_cast<f32x4*>(As + p * AP + (idx - p * A_CH) * 4) = v;
     }
 #pragma unroll
     for (int i = 0; i < B_LOADS; ++i) {
@@ -589,17 +606,20 @@ __global__ __launch_bounds__(THREADS) void linear_wgrad_smallp_kernel(
 // dX = dY W (tiles of the implicit-GEMM program, K tile 64, unsplit), the others the weight (and bias) gradient with the
 // few-rows program above.  The two are independent - both only read dY - and each occupies a handful of CUs, so sharing a
 // launch removes one ~8 us dependent launch per layer (there are ~270 such layers in a step).
-template <bool UNI>
+// AMASK: dY is the gradient of relu(x w^T + b); ymask is that layer's saved output and both roles apply the ReLU mask while
+// they stage dY (no separate relu-backward launch, no masked copy of dY in memory).
+template <bool UNI, bool AMASK>
 __global__ __launch_bounds__(THREADS) void linear_bwd_fused_kernel(
-    const float* __restrict__ dY, const float* __restrict__ W, const float* __restrict__ X,
+    const float* __restrict__ dY, const float* __restrict__ W, const float* __restrict__ X, const float* __restrict__ ymask,
     float* __restrict__ dX, float* __restrict__ dw, float* __restrict__ dbias,
     ConvShape gd, unsigned dgrad_tiles, int P, int Co, int Ci, int want_bias, int accumulate)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     if (blockIdx.x < dgrad_tiles)
-        igemm_tile<64, 64, true, 64, UNI>(dY, W, nullptr, nullptr, dX, gd, 0, lds, blockIdx.x, dgrad_tiles, 0);
+        igemm_tile<64, 64, true, 64, UNI, AMASK>(dY, W, nullptr, nullptr, dX, gd, 0, lds, blockIdx.x, dgrad_tiles, 0, ymask);
     else
-        smallp_tile<64, 64>(dY, X, dw, dbias, P, Co, Ci, want_bias, accumulate, lds, blockIdx.x - dgrad_tiles, gridDim.x - dgrad_tiles);
+        smallp_tile<64, 64, AMASK>(dY, X, dw, dbias, P, Co, Ci, want_bias, accumulate, lds, blockIdx.x - dgrad_tiles,
+                                   gridDim.x - dgrad_tiles, ymask);
 }
 
 // dW (+)= sum_z part[z][0:nw],  dbias (+)= sum_z part[z][nw:nw+nb]   (part rows are nw+nb floats long)
@@ -933,9 +953,10 @@ PHNET_API int phnet_linear_bwd_fusable(int64_t M, int64_t K, int64_t N) { return
 
 // Backward of y = x w^T (+ b) for few rows, one launch: dx [M][K] = dy w;  dw [N][K] and dbias [N] (optional) = dy^T x,
 // column sums of dy - overwritten or, with accumulate = 1, added to.  dy [M][N], x [M][K], w [N][K], all row-major.
+// relu_y (optional, [M][N]): the layer's saved output when it ended in a ReLU - dy is then masked by relu_y > 0 on the fly.
 // Only for shapes with phnet_linear_bwd_fusable(M, K, N) == 1 (PHNET_ERR_ARG otherwise).
-PHNET_API int phnet_linear_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, float* dbias,
-                               int32_t M, int32_t K, int32_t N, int32_t accumulate, void* stream)
+PHNET_API int phnet_linear_bwd(const float* dy, const float* x, const float* w, const float* relu_y, float* dx, float* dw,
+                               float* dbias, int32_t M, int32_t K, int32_t N, int32_t accumulate, void* stream)
 {
     if (!linear_bwd_fusable(M, K, N) || !dy || !x || !w || !dx || !dw) return PHNET_ERR_ARG;
     ConvShape g{};
@@ -952,17 +973,21 @@ PHNET_API int phnet_linear_bwd(const float* dy, const float* x, const float* w, 
     static bool attr = false;
     if (!attr) {
         const int cap = (int)((size_t)SMALLP_MAX * 68 * 2 * sizeof(float));
-        if (hipFuncSetAttribute((const void*)linear_bwd_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
-            hipFuncSetAttribute((const void*)linear_bwd_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess)
-            return PHNET_ERR_LAUNCH;
+        const void* fns[4] = {(const void*)linear_bwd_fused_kernel<true, true>, (const void*)linear_bwd_fused_kernel<true, false>,
+                              (const void*)linear_bwd_fused_kernel<false, true>, (const void*)linear_bwd_fused_kernel<false, false>};
+        for (const void* f : fns)
+            if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess) return PHNET_ERR_LAUNCH;
         attr = true;
     }
     hipStream_t st = (hipStream_t)stream;
-    if (N % 64 == 0 && g_uniform_tap)
-        hipLaunchKernelGGL((linear_bwd_fused_kernel<true>), dim3(dt + wt), dim3(THREADS), lds, st, dy, w, x, dx, dw, dbias, g, dt,
-                           (int)M, (int)N, (int)K, dbias != nullptr, accumulate);
-    else
-        hipLaunchKernelGGL((linear_bwd_fused_kernel<false>), dim3(dt + wt), dim3(THREADS), lds, st, dy, w, x, dx, dw, dbias, g, dt,
-                           (int)M, (int)N, (int)K, dbias != nullptr, accumulate);
+    const bool uni = N % 64 == 0 && g_uniform_tap;
+#define PHNET_LAUNCH_BWD(U_, A_)                                                                                        \
+    hipLaunchKernelGGL((linear_bwd_fused_kernel<U_, A_>), dim3(dt + wt), dim3(THREADS), lds, st, dy, w, x, relu_y, dx, dw, \
+                       dbias, g, dt, (int)M, (int)N, (int)K, dbias != nullptr, accumulate)
+    if (uni && relu_y) PHNET_LAUNCH_BWD(true, true);
+    else if (uni) PHNET_LAUNCH_BWD(true, false);
+    else if (relu_y) PHNET_LAUNCH_BWD(false, true);
+    else PHNET_LAUNCH_BWD(false, false);
+#undef PHNET_LAUNCH_BWD
     return phnet_launch_status();
 }

@@ -46,14 +46,15 @@ class _Linear(torch.autograd.Function):
         if n4 != n:
             g = torch.cat([g, g.new_zeros(g.shape[0], n4 - n)], 1)
         g = g.contiguous()
-        if ctx.relu:
-            g = K.relu_bwd(g, y)
         want_b = ctx.has_b and ctx.needs_input_grad[2]
         if (ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and ctx.w_direct is not None and
                 (not want_b or ctx.b_direct is not None) and K.linear_bwd_fusable(g.shape[0], x2.shape[1], n4)):
-            # few-rows layer with arena / sink destinations: data, weight and bias gradient from ONE launch
-            dx = K.linear_bwd(g, x2, w, ctx.w_direct, ctx.b_direct if want_b else None, accumulate=True)
+            # few-rows layer with arena / sink destinations: ReLU mask, data, weight and bias gradient from ONE launch
+            dx = K.linear_bwd(g, x2, w, ctx.w_direct, ctx.b_direct if want_b else None, accumulate=True,
+                              relu_y=y if ctx.relu else None)
             return dx.view(ctx.xshape), None, None, None, None
+        if ctx.relu:
+            g = K.relu_bwd(g, y)
         dx = K.linear_dgrad(g, w).view(ctx.xshape) if ctx.needs_input_grad[0] else None
         dw = db = None
         if ctx.needs_input_grad[1]:

@@ -196,14 +196,16 @@ def linear_bwd_fusable(m: int, k: int, n: int) -> bool:
     return bool(lib().phnet_linear_bwd_fusable(m, k, n))
 
 
-def linear_bwd(dy2d, x2d, w, dw: torch.Tensor, dbias: Optional[torch.Tensor], accumulate: bool):
-    """dx = dy @ w and dw (+)= dy.T @ x (+ dbias) in one launch (few-rows Linear layers); returns dx."""
+def linear_bwd(dy2d, x2d, w, dw: torch.Tensor, dbias: Optional[torch.Tensor], accumulate: bool, relu_y: Optional[torch.Tensor] = None):
+    """dx = dy @ w and dw (+)= dy.T @ x (+ dbias) in one launch (few-rows Linear layers); returns dx.
+    relu_y: saved output of a layer that ended in a ReLU - dy is masked by relu_y > 0 inside the kernel."""
     _req(dy2d, name="dy"); _req(x2d, name="x"); _req(w, name="w"); _req(dw, name="dw")
     m, n = dy2d.shape
     k = x2d.shape[1]
     dx = torch.empty((m, k), dtype=torch.float32, device=dy2d.device)
-    _timed_launch(lambda: (f"linear_bwd_fused_kernel<{'true' if n % 64 == 0 else 'false'}>", 0), 4.0 * m * n * k,
-                  lambda: check(lib().phnet_linear_bwd(_ptr(dy2d), _ptr(x2d), _ptr(w), _ptr(dx), _ptr(dw), _ptr(dbias), m, k, n,
+    sym = f"linear_bwd_fused_kernel<{'true' if n % 64 == 0 else 'false'}, {'true' if relu_y is not None else 'false'}>"
+    _timed_launch(lambda: (sym, 0), 4.0 * m * n * k,
+                  lambda: check(lib().phnet_linear_bwd(_ptr(dy2d), _ptr(x2d), _ptr(w), _ptr(relu_y), _ptr(dx), _ptr(dw), _ptr(dbias), m, k, n,
                                                        int(accumulate), _stream()), "phnet_linear_bwd"))
     return dx
 

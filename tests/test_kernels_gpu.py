@@ -525,6 +525,12 @@ def test_linear_backward_fused_launch(ops, M, K, N):
     dx1 = ops.linear_bwd(dev(dy.float()), dev(x.float()), dev(w.float()), dw1, None, accumulate=False)
     assert torch.equal(dx1, dx)
     close(dw1, dy.t() @ x, 3e-5)
+    # layer that ended in a ReLU: the mask of its saved output is applied while dy is staged
+    y = torch.relu(torch.randn(M, N, dtype=torch.float64))
+    gm = dy * (y > 0)
+    dw2, db2 = torch.empty_like(dwd), torch.empty_like(dbd)
+    dx2 = ops.linear_bwd(dev(dy.float()), dev(x.float()), dev(w.float()), dw2, db2, accumulate=False, relu_y=dev(y.float()))
+    close(dx2, gm @ w, 3e-5); close(dw2, gm.t() @ x, 3e-5); close(db2, gm.sum(0), 3e-5)
 
 
 def test_memory_tokens_gate_tail_blend(ops):
