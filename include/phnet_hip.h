@@ -90,7 +90,7 @@ int phnet_conv2d_wgrad(const float* dy, const float* x, float* dw, float* dbias,
                        int32_t stride, int32_t pad, int32_t accumulate, void* workspace, uint64_t ws_bytes, void* stream);
 /* Backward of a Linear layer over few rows (the M = 240 layers of the lane head) as ONE launch: dx [M][K] = dy w and
  * dw [N][K] (+)= dy^T x, dbias [N] (+)= column sums of dy (dbias optional).  dy [M][N], x [M][K], w [N][K] row-major.
- * phnet_linear_bwd_fusable tells whether a shape qualifies (M <= 256, N <= 512, few tiles); otherwise use
+ * phnet_linear_bwd_fusable tells whether a shape qualifies (M <= 256, N <= 640, few tiles); otherwise use
  * phnet_conv2d_dgrad + phnet_conv2d_wgrad. */
 int phnet_linear_bwd_fusable(int64_t M, int64_t K, int64_t N);
 int phnet_linear_bwd(const float* dy, const float* x, const float* w, const float* relu_y, float* dx, float* dw, float* dbias,

@@ -945,7 +945,7 @@ static bool linear_bwd_fusable(long M, long K, long N)
 {
     if (!g_wgrad_smallp || M < 1 || M > SMALLP_MAX || (K & 3) || (N & 3) || K < 4 || N < 4) return false;
     const long wt = ceil_div64(N, 64) * ceil_div64(K, 64), dt = ceil_div64(M, 64) * ceil_div64(K, 64);
-    return wt < g_smallp_max_tiles && N <= 512 && dt <= 256;          // dgrad stays unsplit: reduction length N <= 512
+    return wt < g_smallp_max_tiles && N <= 640 && dt <= 256;          // dgrad stays unsplit: reduction length N <= 640 (gate MLP: 576)
 }
 
 // 1 when phnet_linear_bwd runs (M, K, N) as ONE launch; 0: use phnet_conv2d_dgrad + phnet_conv2d_wgrad instead.
