@@ -182,13 +182,15 @@ int phnet_relu_bwd(const float* dy, const float* y, float* dx, int64_t n, void* 
  * (libs/models/Router.py:72-75) in one launch forward, one backward (+ one reduce).  x/out [N][C][P], C*P <= 3072.
  * params / grads: HOST arrays of 34 device pointers: pre_norm.weight, pre_norm.bias, then per block b = 0..3:
  * conv1.weight [N][9], conv1.bias [N], ln1.weight [C*P], ln1.bias, conv2.weight, conv2.bias, ln2.weight, ln2.bias.
- * saved: phnet_gate_stack_saved_floats() floats written by fwd (NULL = inference), read by bwd. ---- */
+ * saved: phnet_gate_stack_saved_floats() floats written by fwd (NULL = inference), read by bwd.
+ * N planes may cover several frames: plane n belongs to anchor n % anchors (the per-anchor filters are [anchors][9], N % anchors
+ * == 0); the filter gradients of such a batch go through per-plane partials and one more small reduce launch. ---- */
 uint64_t phnet_gate_stack_saved_floats(int32_t N, int32_t C, int32_t P);
 uint64_t phnet_gate_stack_bwd_workspace(int32_t N, int32_t C, int32_t P);
 int phnet_gate_stack_fwd(const float* x, const float* const* params, float* out, float* saved,
-                         int32_t N, int32_t C, int32_t P, float eps, void* stream);
+                         int32_t N, int32_t anchors, int32_t C, int32_t P, float eps, void* stream);
 int phnet_gate_stack_bwd(const float* gout, const float* x, const float* out, const float* const* params,
-                         const float* saved, float* const* grads, int32_t N, int32_t C, int32_t P, float eps,
+                         const float* saved, float* const* grads, int32_t N, int32_t anchors, int32_t C, int32_t P, float eps,
                          int32_t accumulate, void* workspace, uint64_t ws_bytes, void* stream);
 
 /* ---- fused attention core (heads of width 16, Lq/Lk <= 256): replaces the scale/bmm/mask/softmax/dropout/bmm chain inside

@@ -124,23 +124,30 @@ __global__ __launch_bounds__(1024) void gate_tail_bwd_kernel(const float* __rest
                                                             float* __restrict__ dh, float* __restrict__ dw, float* __restrict__ db,
                                                             int N, int K, int accumulate)
 {
-    __shared__ float g[1024];
+    constexpr int CH = 2048;                            // anchors per pass (stage 0 batches all frames of a clip: N = T * 240)
+    __shared__ float g[CH];
     __shared__ float part[16][64];
-    for (int n = threadIdx.x; n < N; n += 1024) {
-        const float o = out[n];
-        g[n] = o > 0.5f ? dout[n] * o * (1.0f - o) : 0.f;
-    }
-    __syncthreads();
     const int kc = threadIdx.x & 63, grp = threadIdx.x >> 6, k = blockIdx.x * 64 + kc;
-    float acc = 0.f;
-    if (k < K) {
-        const float wk = w[k];
-#pragma unroll 4
-        for (int n = grp; n < N; n += 16) {
-            const float gn = g[n];
-            acc += gn * h[(size_t)n * K + k];
-            if (dh) dh[(size_t)n * K + k] = gn * wk;
+    const float wk = k < K ? w[k] : 0.f;
+    float acc = 0.f, bsum = 0.f;
+    for (int base = 0; base < N; base += CH) {
+        const int cnt = min(CH, N - base);
+        __syncthreads();
+        for (int n = threadIdx.x; n < cnt; n += 1024) {
+            const float o = out[base + n];
+            g[n] = o > 0.5f ? dout[base + n] * o * (1.0f - o) : 0.f;
         }
+        __syncthreads();
+        if (k < K) {
+#pragma unroll 4
+            for (int n = grp; n < cnt; n += 16) {
+                const float gn = g[n];
+                acc += gn * h[(size_t)(base + n) * K + k];
+                if (dh) dh[(size_t)(base + n) * K + k] = gn * wk;
+            }
+        }
+        if (blockIdx.x == 0 && grp == 1)
+            for (int n = kc; n < cnt; n += 64) bsum += g[n];
     }
     part[grp][kc] = acc;
     __syncthreads();
@@ -151,9 +158,7 @@ __global__ __launch_bounds__(1024) void gate_tail_bwd_kernel(const float* __rest
         dw[k] = accumulate ? dw[k] + t : t;
     }
     if (blockIdx.x == 0 && grp == 1) {                   // one wavefront: the bias gradient
-        float s = 0.f;
-        for (int n = kc; n < N; n += 64) s += g[n];
-        s = wave_sum(s);
+        const float s = wave_sum(bsum);
         if (kc == 0) db[0] = accumulate ? db[0] + s : s;
     }
 }
@@ -343,11 +348,11 @@ PHNET_API int phnet_gate_tail_fwd(const float* h, const float* w, const float* b
     return phnet_launch_status();
 }
 
-// Backward of phnet_gate_tail_fwd from its output: dh [N][K] (optional), dw [K], db [1] overwritten or accumulated.  N <= 1024.
+// Backward of phnet_gate_tail_fwd from its output: dh [N][K] (optional), dw [K], db [1] overwritten or accumulated.
 PHNET_API int phnet_gate_tail_bwd(const float* dout, const float* out, const float* h, const float* w, float* dh, float* dw, float* db,
                                   int32_t N, int32_t K, int32_t accumulate, void* stream)
 {
-    if (N < 1 || N > 1024 || K < 1 || !dout || !out || !h || !w || !dw || !db) return PHNET_ERR_ARG;
+    if (N < 1 || K < 1 || !dout || !out || !h || !w || !dw || !db) return PHNET_ERR_ARG;
     hipLaunchKernelGGL(gate_tail_bwd_kernel, dim3((K + 63) / 64), dim3(1024), 0, (hipStream_t)stream, dout, out, h, w, dh, dw, db,
                        N, K, accumulate);
     return phnet_launch_status();

@@ -96,11 +96,12 @@ __device__ __forceinline__ void store_plane(float* dst, int CP, const float (&v)
 // planes: [13][N][CP] = s0..s3 | u0..u3 | t0..t3 | (12 unused)   stats: [N][18] = (mu, rs) of LN0, then per block LN1, LN2
 __global__ __launch_bounds__(NT) void gate_stack_fwd_kernel(const float* __restrict__ x, GateParams w, float* __restrict__ out,
                                                             float* __restrict__ planes, float* __restrict__ stats,
-                                                            int N, int C, int P, float eps)
+                                                            int N, int A, int C, int P, float eps)
 {
     extern __shared__ float lds[];                  // 2 planes
     __shared__ float red[2 * NW];
     const int n = blockIdx.x, CP = C * P;
+    const int an = n % A;                            // anchor of this plane: planes of several frames share the A per-anchor filters
     float* P0 = lds;
     float* P1 = lds + CP;
     const size_t plane_off = (size_t)n * CP, slab = (size_t)N * CP;
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(NT) void gate_stack_fwd_kernel(const float* __restr
         if (planes) store_plane(planes + (size_t)b * slab + plane_off, CP, s);            // s_b
         store_plane(P0, CP, s);
         __syncthreads();
-        dwconv_plane(P0, q[0] + n * 9, q[1][n], C, P, CP, false, a);                       // u_b
+        dwconv_plane(P0, q[0] + an * 9, q[1][an], C, P, CP, false, a);                     // u_b
         if (planes) store_plane(planes + (size_t)(4 + b) * slab + plane_off, CP, a);
         plane_stats(a, CP, eps, mu, rs, red);
         if (stats && threadIdx.x == 0) { stats[n * 18 + 2 + 4 * b] = mu; stats[n * 18 + 3 + 4 * b] = rs; }
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(NT) void gate_stack_fwd_kernel(const float* __restr
         }
         store_plane(P1, CP, a);
         __syncthreads();
-        dwconv_plane(P1, q[4] + n * 9, q[5][n], C, P, CP, false, a);                       // t_b
+        dwconv_plane(P1, q[4] + an * 9, q[5][an], C, P, CP, false, a);                     // t_b
         if (planes) store_plane(planes + (size_t)(8 + b) * slab + plane_off, CP, a);
         plane_stats(a, CP, eps, mu, rs, red);
         if (stats && threadIdx.x == 0) { stats[n * 18 + 4 + 4 * b] = mu; stats[n * 18 + 5 + 4 * b] = rs; }
@@ -217,8 +218,8 @@ __device__ __forceinline__ void ln_backward(float (&g)[EPT], const float (&xin)[
 __global__ __launch_bounds__(NT) void gate_stack_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ x,
                                                             const float* __restrict__ out, GateParams w,
                                                             const float* __restrict__ planes, const float* __restrict__ stats,
-                                                            GateGrads dg, float* __restrict__ lnpart,
-                                                            int N, int C, int P, float eps, int accumulate)
+                                                            GateGrads dg, float* __restrict__ lnpart, float* __restrict__ fpart,
+                                                            int N, int A, int C, int P, float eps, int accumulate)
 {
     extern __shared__ float lds[];                  // 2 planes
     __shared__ float red[2 * NW], red10[10 * NW];
@@ -227,6 +228,11 @@ __global__ __launch_bounds__(NT) void gate_stack_bwd_kernel(const float* __restr
     float* P1 = lds + CP;
     const size_t plane_off = (size_t)n * CP, slab = (size_t)N * CP;
     float* lp = lnpart + (size_t)n * 18 * CP;
+    const int an = n % A;
+    // N == A: this workgroup is the only one that touches its anchor's filter gradients - write them directly;
+    // N > A (planes of several frames): per-plane partials [N][8][10] in fpart, folded by gate_filter_grad_reduce_kernel
+    const bool direct_f = N == A;
+    float* fp = fpart + (size_t)n * 80;
     float g[EPT], v[EPT], acc[10];
     load_plane(gout + plane_off, CP, g);
     for (int b = 3; b >= 0; --b) {
@@ -262,9 +268,10 @@ __global__ __launch_bounds__(NT) void gate_stack_bwd_kernel(const float* __restr
         store_plane(P1, CP, g);
         __syncthreads();
         filter_grad_partials(P0, g, C, P, CP, acc);
-        reduce_filter_grad(acc, red10, dq[4] + n * 9, dq[5] + n, accumulate);
+        if (direct_f) reduce_filter_grad(acc, red10, dq[4] + an * 9, dq[5] + an, accumulate);
+        else reduce_filter_grad(acc, red10, fp + (2 * b + 1) * 10, fp + (2 * b + 1) * 10 + 9, 0);
         float dv[EPT];
-        dwconv_plane(P1, q[4] + n * 9, 0.f, C, P, CP, true, dv);
+        dwconv_plane(P1, q[4] + an * 9, 0.f, C, P, CP, true, dv);
 #pragma unroll
         for (int k = 0; k < EPT; ++k) g[k] = v[k] > 0.f ? dv[k] : 0.f;                         // through the inner relu
         // ---- LN1 backward (input u_b, still in a[]) ----
@@ -275,8 +282,9 @@ __global__ __launch_bounds__(NT) void gate_stack_bwd_kernel(const float* __restr
         store_plane(P1, CP, g);
         __syncthreads();
         filter_grad_partials(P0, g, C, P, CP, acc);
-        reduce_filter_grad(acc, red10, dq[0] + n * 9, dq[1] + n, accumulate);
-        dwconv_plane(P1, q[0] + n * 9, 0.f, C, P, CP, true, dv);
+        if (direct_f) reduce_filter_grad(acc, red10, dq[0] + an * 9, dq[1] + an, accumulate);
+        else reduce_filter_grad(acc, red10, fp + (2 * b) * 10, fp + (2 * b) * 10 + 9, 0);
+        dwconv_plane(P1, q[0] + an * 9, 0.f, C, P, CP, true, dv);
 #pragma unroll
         for (int k = 0; k < EPT; ++k) g[k] = dv[k] + gres[k];                                  // + residual path
     }
@@ -312,44 +320,66 @@ __global__ __launch_bounds__(256) void gate_ln_grad_reduce_kernel(const float* _
     *dst = old + (float)s;
 }
 
+// filter gradients of a batch of frames: dst (+)= sum over the N/A planes of anchor a;  fpart [N][8 convs][9 taps + bias]
+// conv c of block b sits at slot 2b + (0: conv1, 1: conv2);  parameter slots: conv1.weight 2+8b, conv1.bias 3+8b,
+// conv2.weight 6+8b, conv2.bias 7+8b
+__global__ __launch_bounds__(256) void gate_filter_grad_reduce_kernel(const float* __restrict__ fpart, GateGrads dg, int N, int A,
+                                                                      int accumulate)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= A * 80) return;
+    const int a = i / 80, r = i - a * 80, conv = r / 10, t = r - conv * 10;
+    const int b = conv >> 1, second = conv & 1;
+    float* dst = t < 9 ? dg.p[2 + 8 * b + (second ? 4 : 0)] + a * 9 + t : dg.p[3 + 8 * b + (second ? 4 : 0)] + a;
+    const float old = accumulate ? *dst : 0.f;
+    float s = 0.f;
+    for (int n = a; n < N; n += A) s += fpart[(size_t)n * 80 + r];
+    *dst = old + s;
+}
+
 bool gate_args_ok(int N, int C, int P) { return N >= 1 && C >= 1 && P >= 1 && (long)C * P <= (long)NT * EPT; }
 
 }  // namespace
 
 PHNET_API uint64_t phnet_gate_stack_saved_floats(int32_t N, int32_t C, int32_t P) { return (uint64_t)12 * N * C * P + (uint64_t)18 * N; }
-PHNET_API uint64_t phnet_gate_stack_bwd_workspace(int32_t N, int32_t C, int32_t P) { return (uint64_t)18 * N * C * P * sizeof(float); }
+PHNET_API uint64_t phnet_gate_stack_bwd_workspace(int32_t N, int32_t C, int32_t P) { return ((uint64_t)18 * N * C * P + (uint64_t)80 * N) * sizeof(float); }
 
 // x [N][C][P] gate input; params: HOST array of 34 device pointers in the order
 //   pre_norm.weight, pre_norm.bias, then for block 0..3: conv1.weight [N][9], conv1.bias [N], ln1.weight [C*P], ln1.bias,
 //   conv2.weight, conv2.bias, ln2.weight, ln2.bias.
 // out [N][C][P]; saved (training, may be NULL): phnet_gate_stack_saved_floats floats = 12 planes [N][C][P] + stats [N][18].
 PHNET_API int phnet_gate_stack_fwd(const float* x, const float* const* params, float* out, float* saved,
-                                   int32_t N, int32_t C, int32_t P, float eps, void* stream)
+                                   int32_t N, int32_t anchors, int32_t C, int32_t P, float eps, void* stream)
 {
-    if (!gate_args_ok(N, C, P) || !x || !params || !out) return PHNET_ERR_ARG;
+    if (!gate_args_ok(N, C, P) || anchors < 1 || N % anchors || !x || !params || !out) return PHNET_ERR_ARG;
     GateParams w;
     for (int i = 0; i < NPARAM; ++i) { w.p[i] = params[i]; if (!params[i]) return PHNET_ERR_ARG; }
     const size_t CP = (size_t)C * P;
     float* stats = saved ? saved + (size_t)12 * N * CP : nullptr;
     hipLaunchKernelGGL(gate_stack_fwd_kernel, dim3(N), dim3(NT), 2 * CP * sizeof(float), (hipStream_t)stream,
-                       x, w, out, saved, stats, N, C, P, eps);
+                       x, w, out, saved, stats, N, anchors, C, P, eps);
     return phnet_launch_status();
 }
 
 // gout [N][C][P] = d loss / d out.  grads: HOST array of 34 device pointers (same order as params) that are
 // overwritten (accumulate=0) or added to (accumulate=1).  workspace >= phnet_gate_stack_bwd_workspace bytes.
 PHNET_API int phnet_gate_stack_bwd(const float* gout, const float* x, const float* out, const float* const* params,
-                                   const float* saved, float* const* grads, int32_t N, int32_t C, int32_t P, float eps,
-                                   int32_t accumulate, void* workspace, uint64_t ws_bytes, void* stream)
+                                   const float* saved, float* const* grads, int32_t N, int32_t anchors, int32_t C, int32_t P,
+                                   float eps, int32_t accumulate, void* workspace, uint64_t ws_bytes, void* stream)
 {
-    if (!gate_args_ok(N, C, P) || !gout || !x || !out || !params || !saved || !grads || !workspace) return PHNET_ERR_ARG;
+    if (!gate_args_ok(N, C, P) || anchors < 1 || N % anchors || !gout || !x || !out || !params || !saved || !grads || !workspace)
+        return PHNET_ERR_ARG;
     const size_t CP = (size_t)C * P;
-    if ((uint64_t)18 * N * CP * sizeof(float) > ws_bytes) return PHNET_ERR_WORKSPACE;
+    if (phnet_gate_stack_bwd_workspace(N, C, P) > ws_bytes) return PHNET_ERR_WORKSPACE;
+    float* fpart = (float*)workspace + (size_t)18 * N * CP;
     GateParams w; GateGrads dg;
     for (int i = 0; i < NPARAM; ++i) { w.p[i] = params[i]; dg.p[i] = grads[i]; if (!params[i] || !grads[i]) return PHNET_ERR_ARG; }
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(gate_stack_bwd_kernel, dim3(N), dim3(NT), 2 * CP * sizeof(float), st,
-                       gout, x, out, w, saved, saved + (size_t)12 * N * CP, dg, (float*)workspace, N, C, P, eps, accumulate);
+                       gout, x, out, w, saved, saved + (size_t)12 * N * CP, dg, (float*)workspace, fpart, N, anchors, C, P, eps, accumulate);
+    if (N != anchors)
+        hipLaunchKernelGGL(gate_filter_grad_reduce_kernel, dim3((anchors * 80 + 255) / 256), dim3(256), 0, st, fpart, dg, N, anchors,
+                           accumulate);
     hipLaunchKernelGGL(gate_ln_grad_reduce_kernel, dim3((unsigned)ceil_div64(18L * CP, 256)), dim3(256), 0, st,
                        (const float*)workspace, dg, N, (int)CP, accumulate);
     return phnet_launch_status();

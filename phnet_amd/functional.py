@@ -204,12 +204,12 @@ class _GateStack(torch.autograd.Function):
     arena when every parameter is arena-backed, otherwise returned to autograd."""
 
     @staticmethod
-    def forward(ctx, x, eps, *params):
+    def forward(ctx, x, eps, anchors, *params):
         xc = x.contiguous()
         pc = [p.contiguous() for p in params]
-        need = any(ctx.needs_input_grad[2:])          # (grad mode is off inside forward; ask autograd instead)
-        out, saved = K.gate_stack_fwd(xc, pc, eps, need)
-        ctx.eps = eps
+        need = any(ctx.needs_input_grad[3:])          # (grad mode is off inside forward; ask autograd instead)
+        out, saved = K.gate_stack_fwd(xc, pc, eps, need, anchors)
+        ctx.eps, ctx.anchors = eps, anchors
         ctx.direct = [direct_grad(p) for p in params]
         ctx.pshapes = [p.shape for p in params]
         ctx.save_for_backward(xc, out, saved, *pc)
@@ -219,15 +219,16 @@ class _GateStack(torch.autograd.Function):
     def backward(ctx, gout):
         xc, out, saved, *pc = ctx.saved_tensors
         if all(d is not None for d in ctx.direct):
-            K.gate_stack_bwd(gout.contiguous(), xc, out, pc, saved, ctx.direct, ctx.eps, True)
-            return (None, None) + (None,) * len(pc)
+            K.gate_stack_bwd(gout.contiguous(), xc, out, pc, saved, ctx.direct, ctx.eps, True, ctx.anchors)
+            return (None, None, None) + (None,) * len(pc)
         grads = [torch.empty_like(p) for p in pc]
-        K.gate_stack_bwd(gout.contiguous(), xc, out, pc, saved, grads, ctx.eps, False)
-        return (None, None) + tuple(g.view(s) for g, s in zip(grads, ctx.pshapes))
+        K.gate_stack_bwd(gout.contiguous(), xc, out, pc, saved, grads, ctx.eps, False, ctx.anchors)
+        return (None, None, None) + tuple(g.view(s) for g, s in zip(grads, ctx.pshapes))
 
 
-def gate_stack(x, params, eps: float = 1e-5):
-    return _GateStack.apply(x, eps, *params)
+def gate_stack(x, params, eps: float = 1e-5, anchors=None):
+    """x [N,C,P] planes; `anchors`: number of per-anchor filters when the planes cover several frames (N % anchors == 0)."""
+    return _GateStack.apply(x, eps, anchors, *params)
 
 
 class _LaneUpdate(torch.autograd.Function):

@@ -520,23 +520,26 @@ def _ptr_array(tensors):
     return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
 
-def gate_stack_fwd(x, params, eps: float, save: bool):
-    """x [N,C,P]; params: the 34 tensors in the C-ABI order.  Returns (out, saved or None)."""
+def gate_stack_fwd(x, params, eps: float, save: bool, anchors: Optional[int] = None):
+    """x [N,C,P] (N a multiple of `anchors`: planes of several frames); params: the 34 tensors in the C-ABI order.
+    Returns (out, saved or None)."""
     _req(x, name="x")
     n, c, p = x.shape
+    anchors = n if anchors is None else anchors
     out = torch.empty_like(x)
     saved = torch.empty(lib().phnet_gate_stack_saved_floats(n, c, p), dtype=torch.float32, device=x.device) if save else None
-    check(lib().phnet_gate_stack_fwd(_ptr(x), _ptr_array(params), _ptr(out), _ptr(saved), n, c, p, eps, _stream()),
+    check(lib().phnet_gate_stack_fwd(_ptr(x), _ptr_array(params), _ptr(out), _ptr(saved), n, anchors, c, p, eps, _stream()),
           "phnet_gate_stack_fwd")
     return out, saved
 
 
-def gate_stack_bwd(gout, x, out, params, saved, grads, eps: float, accumulate: bool):
+def gate_stack_bwd(gout, x, out, params, saved, grads, eps: float, accumulate: bool, anchors: Optional[int] = None):
     _req(gout, name="gout")
     n, c, p = x.shape
+    anchors = n if anchors is None else anchors
     ws = workspace(lib().phnet_gate_stack_bwd_workspace(n, c, p), x.device, 3)
     check(lib().phnet_gate_stack_bwd(_ptr(gout), _ptr(x), _ptr(out), _ptr_array(params), _ptr(saved), _ptr_array(grads),
-                                     n, c, p, eps, int(accumulate), _ptr(ws), ws.numel(), _stream()), "phnet_gate_stack_bwd")
+                                     n, anchors, c, p, eps, int(accumulate), _ptr(ws), ws.numel(), _stream()), "phnet_gate_stack_bwd")
 
 
 def _rng_args(rng):

@@ -28,17 +28,16 @@ class AdaptiveRouter4Lane(nn.Module):
         self.DWNets = nn.ModuleList(copy.deepcopy(net) for _ in range(stages))
 
     def forward(self, xs: torch.Tensor, stage: int, thres: float = 0.5) -> torch.Tensor:
-        """xs [1,N,C,P] (detached by the caller) -> [1,N,1] in [0.5, 1)."""
+        """xs [B,N,C,P] (detached by the caller; B frames share the N per-anchor filters) -> [B,N,1] in [0.5, 1)."""
         b, n, c, p = xs.shape
-        assert b == 1
         pn = self.pre_norm[stage]
         params = [pn.weight, pn.bias]
         for blk in self.DWNets[stage]:
             params += [blk[0].weight, blk[0].bias, blk[1].weight, blk[1].bias, blk[3].weight, blk[3].bias, blk[4].weight, blk[4].bias]
-        x = PF.gate_stack(xs.reshape(n, c, p), params, eps=pn.eps)        # one fused launch (csrc/gate.hip)
+        x = PF.gate_stack(xs.reshape(b * n, c, p), params, eps=pn.eps, anchors=n)      # one fused launch (csrc/gate.hip)
         mlp = self.layers[stage]
-        h = PF.linear(x.reshape(n, c * p), mlp[0].weight, mlp[0].bias, relu=True)
+        h = PF.linear(x.reshape(b * n, c * p), mlp[0].weight, mlp[0].bias, relu=True)
         if mlp[2].out_features == 1:                                     # ReLU before the sigmoid (Router.py:76-80)
-            return PF.gate_tail(h, mlp[2].weight, mlp[2].bias).view(1, n, 1)
+            return PF.gate_tail(h, mlp[2].weight, mlp[2].bias).view(b, n, 1)
         h = PF.linear(h, mlp[2].weight, mlp[2].bias, relu=True)
-        return torch.sigmoid(h).view(1, n, -1)
+        return torch.sigmoid(h).view(b, n, -1)

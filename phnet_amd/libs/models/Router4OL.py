@@ -180,17 +180,17 @@ class DetNetV2(nn.Module):
 
     # ---- one refinement stage / one frame ---------------------------------------------------------------------
     def stage_front(self, fmap, stage, priors, on_map, pro_feat):
-        """The part of a stage that needs no other frame: ROI pooling, dynamic head, branch A.  Batched over B frames:
-        fmap [B,h,w,C]; priors [B,N,6+S]; on_map [B,N,P]; pro_feat [B,N,C].  Returns dict(roi_cp, local, pred_a, lines_a)."""
+        """The part of a stage that needs no other frame: ROI pooling, routing gate, dynamic head, branch A.  Batched over B frames:
+        fmap [B,h,w,C]; priors [B,N,6+S]; on_map [B,N,P]; pro_feat [B,N,C].  Returns dict(gate, local, pred_a, lines_a)."""
         roi, roi_cp = PF.roi_pool(fmap, on_map, self.prior_feat_ys)                  # [B,N,P,C], [B,N,C,P]
+        gate = self.router(roi_cp, stage)                                            # [B,N,1]
         local = self.DHead_series[stage](pro_feat, roi)                              # [B,N,C]
         pred_a, lines_a = self.forward_first(local, priors)
-        return dict(roi_cp=roi_cp, local=local, pred_a=pred_a, lines_a=lines_a)
+        return dict(gate=gate, local=local, pred_a=pred_a, lines_a=lines_a)
 
     def stage_back(self, front, stage, priors, memory):
-        """Gate and branch B of ONE frame on top of its stage_front results (all [1,...])."""
-        gate = self.router(front["roi_cp"], stage)                                   # [1,N,1]
-        local = front["local"]
+        """Branch B of ONE frame on top of its stage_front results (all [1,...])."""
+        gate, local = front["gate"], front["local"]
         pos = self.PositionEmbedding.embed.weight.unsqueeze(1)                       # [N,1,C]
         attn = torch.cat([local.transpose(0, 1), pos], dim=-1)                       # [N,1,2C]
         pred_b, lines_b = self.forward_second(memory, attn, stage, priors)
@@ -203,7 +203,7 @@ class DetNetV2(nn.Module):
 
     def stage0_all_frames(self, fmaps0):
         """Stage 0 of every frame starts from the same learned anchors and embeddings, and only its branch B looks at
-        earlier frames - so ROI pooling, dynamic head and branch A of stage 0 run ONCE for the whole clip (GEMM rows
+        earlier frames - so ROI pooling, routing gate, dynamic head and branch A of stage 0 run ONCE for the whole clip (GEMM rows
         T*N instead of N, a fifth of the launches).  fmaps0 [T,h,w,C] = the stage-0 pyramid level of all frames.
         Returns a list over frames of stage_front dicts ([1,...] views; their gradients meet in one cat)."""
         T = fmaps0.shape[0]

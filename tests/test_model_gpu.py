@@ -385,7 +385,8 @@ def test_arena_direct_accumulation_equals_autograd_accumulation():
         for (k, a), (_, b) in zip(model.named_parameters(), ref.named_parameters()):
             assert a.grad.data_ptr() >= arena.flat.data_ptr() and a.grad.data_ptr() < arena.flat.data_ptr() + arena.flat.numel() * 4, k
             scale = float(b.grad.abs().max()) + 1e-6
-            assert float((a.grad - b.grad).abs().max()) <= 2e-3 * scale, (k, float((a.grad - b.grad).abs().max()), scale)
+            # (+1e-6: the depth-wise conv biases in front of a LayerNorm have pure-noise gradients of that size)
+            assert float((a.grad - b.grad).abs().max()) <= 2e-3 * scale + 1e-6, (k, float((a.grad - b.grad).abs().max()), scale)
     finally:
         arena.release()
 
