@@ -75,13 +75,20 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(const float* __restrict__ 
     __shared__ __attribute__((aligned(16))) float Ks[MAXK][DP], Vs[MAXK][DP];
     __shared__ unsigned char valid[MAXK];
     const int h = blockIdx.x, row = blockIdx.y * ROWS + threadIdx.x / LPR, part = threadIdx.x % LPR;
+    // the query row first (branch-free float4 loads): its latency overlaps the K/V staging instead of following the barrier
+    const bool live = row < g.Lq;
+    float qr[D];
+    {
+        const f4* qp = reinterpret_cast<const f4*>(q + (size_t)(live ? row : 0) * g.sq + h * D);
+#pragma unroll
+        for (int c = 0; c < D / 4; ++c) {
+            const f4 t = qp[c];
+            qr[4 * c] = t.x * g.scale; qr[4 * c + 1] = t.y * g.scale; qr[4 * c + 2] = t.z * g.scale; qr[4 * c + 3] = t.w * g.scale;
+        }
+    }
     stage_pair(k, g.sk, v, g.sv, h, g.Lk, Ks, Vs, 1.0f);
     for (int i = threadIdx.x; i < g.Lk; i += NT) valid[i] = key_valid ? key_valid[i] : 1;
     __syncthreads();
-    const bool live = row < g.Lq;
-    float qr[D];
-#pragma unroll
-    for (int d = 0; d < D; ++d) qr[d] = live ? q[(size_t)row * g.sq + h * D + d] * g.scale : 0.f;
     float m = -INFINITY, l = 0.f, acc[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) acc[d] = 0.f;
@@ -131,18 +138,25 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(const float* __restrict__ 
     const int row = tile * ROWS + threadIdx.x / LPR, part = threadIdx.x % LPR;
     for (int i = threadIdx.x; i < g.Lk; i += NT) valid[i] = key_valid ? key_valid[i] : 1;
     if (dq_role) {
-        stage_pair(k, g.sk, v, g.sv, h, g.Lk, As, Bs, 1.0f);
-        __syncthreads();
+        // this row's q, dO, O and lse first: their latency overlaps the K/V staging
         const bool live = row < g.Lq;
         const int r = live ? row : 0;
         float qr[D], dor[D], delta = 0.f;
+        {
+            const f4* qp = reinterpret_cast<const f4*>(q + (size_t)r * g.sq + h * D);
+            const f4* gp = reinterpret_cast<const f4*>(dout + (size_t)r * g.so + h * D);
+            const f4* op = reinterpret_cast<const f4*>(o + (size_t)r * g.so + h * D);
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            qr[d] = q[(size_t)r * g.sq + h * D + d] * g.scale;
-            dor[d] = dout[(size_t)r * g.so + h * D + d];
-            delta += dor[d] * o[(size_t)r * g.so + h * D + d];
+            for (int c = 0; c < D / 4; ++c) {
+                const f4 tq = qp[c], tg = gp[c], to = op[c];
+                qr[4 * c] = tq.x * g.scale; qr[4 * c + 1] = tq.y * g.scale; qr[4 * c + 2] = tq.z * g.scale; qr[4 * c + 3] = tq.w * g.scale;
+                dor[4 * c] = tg.x; dor[4 * c + 1] = tg.y; dor[4 * c + 2] = tg.z; dor[4 * c + 3] = tg.w;
+                delta += (tg.x * to.x + tg.y * to.y) + (tg.z * to.z + tg.w * to.w);
+            }
         }
         const float L = lse[(size_t)h * g.Lq + r];
+        stage_pair(k, g.sk, v, g.sv, h, g.Lk, As, Bs, 1.0f);
+        __syncthreads();
         const unsigned char* kp = keep ? keep + ((size_t)h * g.Lq + r) * g.Lk : nullptr;
         const uint64_t rbase = ((uint64_t)h * g.Lq + r) * g.Lk;
         float acc[D];
@@ -224,7 +238,7 @@ PHNET_API int phnet_attention_fwd(const float* q, const float* k, const float* v
                                   const uint64_t* rng_state, uint64_t rng_call, float drop_p, void* stream)
 {
     if (!attn_ok(Lq, Lk, H, E) || !q || !k || !v || !o || !lse || drop_p < 0.f || drop_p >= 1.f) return PHNET_ERR_ARG;
-    if (!aligned16(k, sk) || !aligned16(v, sv)) return PHNET_ERR_ARG;
+    if (!aligned16(k, sk) || !aligned16(v, sv) || !aligned16(q, sq)) return PHNET_ERR_ARG;
     const DropRng rng = keep ? DropRng{nullptr, 0, 0u} : phnet_make_rng(rng_state, rng_call, drop_p);
     AttnShape g{Lq, Lk, H, sq, sk, sv, so, 1.0f / sqrtf((float)D), keep ? keep_scale : (rng.thresh ? 1.0f / (1.0f - drop_p) : 1.0f)};
     hipLaunchKernelGGL(attn_fwd_kernel, dim3(H, (Lq + ROWS - 1) / ROWS), dim3(NT), 0, (hipStream_t)stream,
@@ -241,7 +255,7 @@ PHNET_API int phnet_attention_bwd(const float* q, const float* k, const float* v
 {
     if (!attn_ok(Lq, Lk, H, E) || !q || !k || !v || !o || !dout || !lse || !dq || !dk || !dv || drop_p < 0.f || drop_p >= 1.f)
         return PHNET_ERR_ARG;
-    if (!aligned16(k, sk) || !aligned16(v, sv) || !aligned16(q, sq) || !aligned16(dout, so)) return PHNET_ERR_ARG;
+    if (!aligned16(k, sk) || !aligned16(v, sv) || !aligned16(q, sq) || !aligned16(dout, so) || !aligned16(o, so)) return PHNET_ERR_ARG;
     const DropRng rng = keep ? DropRng{nullptr, 0, 0u} : phnet_make_rng(rng_state, rng_call, drop_p);
     AttnShape g{Lq, Lk, H, sq, sk, sv, so, 1.0f / sqrtf((float)D), keep ? keep_scale : (rng.thresh ? 1.0f / (1.0f - drop_p) : 1.0f)};
     const int qt = (Lq + ROWS - 1) / ROWS, kt = (Lk + ROWS - 1) / ROWS;
