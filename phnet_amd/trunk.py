@@ -52,8 +52,6 @@ def _conv_bn(tape: list, x, conv: nn.Conv2d, bn, training: bool, relu: bool, res
     else:
         rec.y, rec.sm, rec.si = K.bn_fwd(rec.c, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
                                          training, bn.eps, mom, residual, relu)
-    if training and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked += 1
     rec.relu, rec.has_res = relu, residual is not None
     tape.append(rec)
     return rec.y
@@ -89,6 +87,9 @@ class EncoderFunction(torch.autograd.Function):
             K.upsample_add_(lats[i - 1], lats[i])
         outs = [K.conv2d_fwd(l, w, m.conv.bias.detach(), 1, 1) for l, w, m in zip(lats, out_w, neck.fpn_convs)]
         if training:
+            counters = [r.bn.num_batches_tracked for r in tape if r.bn.num_batches_tracked is not None]
+            if counters:
+                torch._foreach_add_(counters, 1)               # one multi-tensor launch for the 36 BatchNorm step counters
             ctx.enc, ctx.tape, ctx.argmax, ctx.stem_shape = enc, tape, argmax, stem_shape
             ctx.feats, ctx.lats, ctx.lat_w, ctx.out_w = feats, lats, lat_w, out_w
             ctx.index = {id(p): i for i, p in enumerate(enc.parameters())}
