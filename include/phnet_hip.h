@@ -200,14 +200,15 @@ int phnet_gate_stack_bwd(const float* gout, const float* x, const float* out, co
  * drop_p > 0 the mask is drawn in the kernel instead: element (h, q, k) of dropout site rng_call is kept iff a splitmix64
  * hash of (*rng_state, rng_call, element index) clears drop_p * 2^32, scale 1/(1-drop_p); the backward recomputes the
  * same bits (F.dropout inside nn.MultiheadAttention).  *rng_state is a device counter the caller bumps once per step.
- * lse [H][Lq]. ---- */
+ * lse [H][Lq].  B clips per launch: clip b owns rows [b*Lq, (b+1)*Lq) of q/o/dq and [b*Lk, (b+1)*Lk) of k/v/dk/dv; key_valid
+ * [B][Lk], keep [B][H][Lq][Lk], lse [B][H][Lq]. ---- */
 int phnet_attention_fwd(const float* q, const float* k, const float* v, const uint8_t* key_valid, const uint8_t* keep,
-                        float* o, float* lse, int32_t Lq, int32_t Lk, int32_t H, int32_t E,
+                        float* o, float* lse, int32_t B, int32_t Lq, int32_t Lk, int32_t H, int32_t E,
                         int64_t sq, int64_t sk, int64_t sv, int64_t so, float keep_scale,
                         const uint64_t* rng_state, uint64_t rng_call, float drop_p, void* stream);
 int phnet_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* dout,
                         const float* lse, const uint8_t* key_valid, const uint8_t* keep,
-                        float* dq, float* dk, float* dv, int32_t Lq, int32_t Lk, int32_t H, int32_t E,
+                        float* dq, float* dk, float* dv, int32_t B, int32_t Lq, int32_t Lk, int32_t H, int32_t E,
                         int64_t sq, int64_t sk, int64_t sv, int64_t so, int64_t sdq, int64_t sdk, int64_t sdv,
                         float keep_scale, const uint64_t* rng_state, uint64_t rng_call, float drop_p, void* stream);
 
@@ -227,7 +228,7 @@ int phnet_gelu_dropout_bwd(const float* dy, const float* x, float* dx, int64_t n
  * gate tail (Router.py:76-80): gate = sigmoid(relu(h . w + b)) and its backward from the saved output.
  * stage hand-over (Router4OL.py:298-302): blended priors and their sampled x positions. ---- */
 int phnet_memory_tokens(const float* feat, const int64_t* rows, float* tokens, uint8_t* valid,
-                        int32_t N, int32_t E, int32_t L, void* stream);
+                        int32_t B, int32_t N, int32_t E, int32_t L, void* stream);      /* B clips: leading dimension of all four */
 int phnet_gate_tail_fwd(const float* h, const float* w, const float* b, float* out, int32_t N, int32_t K, void* stream);
 int phnet_gate_tail_bwd(const float* dout, const float* out, const float* h, const float* w, float* dh, float* dw, float* db,
                         int32_t N, int32_t K, int32_t accumulate, void* stream);

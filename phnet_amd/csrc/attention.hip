@@ -19,7 +19,7 @@ constexpr int LPR = 16;               // lanes per row: each walks every 16th ke
 constexpr int ROWS = NT / LPR;        // 16 rows (queries or keys) per workgroup -> 8 heads x 15 tiles = 120+ workgroups per launch
 constexpr int MAXK = 256;             // keys per head held in LDS
 
-struct AttnShape { int Lq, Lk, H; long sq, sk, sv, so; float scale, keep_scale; };
+struct AttnShape { int Lq, Lk, H; long sq, sk, sv, so; float scale, keep_scale; };      // gridDim.z = batch: clip b owns rows [b*Lq, (b+1)*Lq) / [b*Lk, (b+1)*Lk)
 
 constexpr int DP = D + 4;              // LDS row pitch: 16-byte aligned rows (b128 access), 4 consecutive rows on distinct banks
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -75,6 +75,12 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(const float* __restrict__ 
     __shared__ __attribute__((aligned(16))) float Ks[MAXK][DP], Vs[MAXK][DP];
     __shared__ unsigned char valid[MAXK];
     const int h = blockIdx.x, row = blockIdx.y * ROWS + threadIdx.x / LPR, part = threadIdx.x % LPR;
+    {   // batch element blockIdx.z: contiguous row blocks of q/o and of k/v
+        const size_t b = blockIdx.z;
+        q += b * g.Lq * g.sq; k += b * g.Lk * g.sk; v += b * g.Lk * g.sv; o += b * g.Lq * g.so; lse += b * g.H * g.Lq;
+        if (key_valid) key_valid += b * g.Lk;
+        if (keep) keep += b * g.H * g.Lq * g.Lk;
+    }
     // the query row first (branch-free float4 loads): its latency overlaps the K/V staging instead of following the barrier
     const bool live = row < g.Lq;
     float qr[D];
@@ -93,7 +99,7 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(const float* __restrict__ 
 #pragma unroll
     for (int d = 0; d < D; ++d) acc[d] = 0.f;
     const unsigned char* kp = keep ? keep + ((size_t)h * g.Lq + (live ? row : 0)) * g.Lk : nullptr;
-    const uint64_t seed = phnet_rng_seed(rng), rbase = ((uint64_t)h * g.Lq + (live ? row : 0)) * g.Lk;
+    const uint64_t seed = phnet_rng_seed(rng), rbase = (((uint64_t)blockIdx.z * g.H + h) * g.Lq + (live ? row : 0)) * g.Lk;
     for (int kk = part; kk < g.Lk; kk += LPR) {
         if (!valid[kk]) continue;
         const float s = dot16(qr, Ks[kk]);
@@ -133,6 +139,14 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(const float* __restrict__ 
     __shared__ float Dl[MAXK], Ls[MAXK];                   // role 1: rowsum(dO*O), lse per query
     __shared__ unsigned char valid[MAXK];
     const int h = blockIdx.x;
+    {
+        const size_t b = blockIdx.z;
+        q += b * g.Lq * g.sq; k += b * g.Lk * g.sk; v += b * g.Lk * g.sv; o += b * g.Lq * g.so; dout += b * g.Lq * g.so;
+        lse += b * g.H * g.Lq; dq += b * g.Lq * sdq; dk += b * g.Lk * sdk; dv += b * g.Lk * sdv;
+        if (key_valid) key_valid += b * g.Lk;
+        if (keep) keep += b * g.H * g.Lq * g.Lk;
+    }
+    const uint64_t ebase = (uint64_t)blockIdx.z * g.H * g.Lq * g.Lk;        // element index base of the dropout generator
     const bool dq_role = (int)blockIdx.y < q_tiles;
     const int tile = dq_role ? blockIdx.y : blockIdx.y - q_tiles;
     const int row = tile * ROWS + threadIdx.x / LPR, part = threadIdx.x % LPR;
@@ -158,7 +172,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(const float* __restrict__ 
         stage_pair(k, g.sk, v, g.sv, h, g.Lk, As, Bs, 1.0f);
         __syncthreads();
         const unsigned char* kp = keep ? keep + ((size_t)h * g.Lq + r) * g.Lk : nullptr;
-        const uint64_t rbase = ((uint64_t)h * g.Lq + r) * g.Lk;
+        const uint64_t rbase = ebase + ((uint64_t)h * g.Lq + r) * g.Lk;
         float acc[D];
 #pragma unroll
         for (int d = 0; d < D; ++d) acc[d] = 0.f;
@@ -205,7 +219,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(const float* __restrict__ 
                 const float s = dot16(kr, As[qq]), dp = dot16(vr, Bs[qq]);
                 const float p = expf(s - Ls[qq]);
                 const uint64_t ei = ((uint64_t)h * g.Lq + qq) * g.Lk + r;
-                const bool kept = keep ? keep[ei] != 0 : (!rng.thresh || phnet_rng_keep(seed, ei, rng.thresh));
+                const bool kept = keep ? keep[ei] != 0 : (!rng.thresh || phnet_rng_keep(seed, ebase + ei, rng.thresh));
                 const float pd = kept ? p * g.keep_scale : 0.f;       // dropped attention weight
                 const float ds = p * ((kept ? dp * g.keep_scale : 0.f) - Dl[qq]);
 #pragma unroll
@@ -228,20 +242,22 @@ bool aligned16(const void* p, int64_t stride) { return ((uintptr_t)p & 15) == 0 
 
 }  // namespace
 
+// B clips in one launch: clip b owns rows [b*Lq, (b+1)*Lq) of q / o / dq and [b*Lk, (b+1)*Lk) of k / v / dk / dv; key_valid
+// u8[B][Lk], keep u8[B][H][Lq][Lk], lse [B][H][Lq].  Per clip:
 // q [Lq][.] row stride sq, k/v [Lk][.] row strides sk/sv (heads packed along the row: column h*16+d); o [Lq][.] stride so;
 // key_valid (optional) u8[Lk]; dropout of the attention weights either by an explicit mask keep u8[H][Lq][Lk] (kept weights
 // scaled by keep_scale) or, when keep is NULL and rng_state/drop_p are given, by the counter-based mask of common.h
 // (site id rng_call, scale 1/(1-p)); lse [H][Lq] saved for the backward.  Lq, Lk <= 256, head width 16.
 PHNET_API int phnet_attention_fwd(const float* q, const float* k, const float* v, const uint8_t* key_valid, const uint8_t* keep,
-                                  float* o, float* lse, int32_t Lq, int32_t Lk, int32_t H, int32_t E,
+                                  float* o, float* lse, int32_t B, int32_t Lq, int32_t Lk, int32_t H, int32_t E,
                                   int64_t sq, int64_t sk, int64_t sv, int64_t so, float keep_scale,
                                   const uint64_t* rng_state, uint64_t rng_call, float drop_p, void* stream)
 {
-    if (!attn_ok(Lq, Lk, H, E) || !q || !k || !v || !o || !lse || drop_p < 0.f || drop_p >= 1.f) return PHNET_ERR_ARG;
+    if (B < 1 || !attn_ok(Lq, Lk, H, E) || !q || !k || !v || !o || !lse || drop_p < 0.f || drop_p >= 1.f) return PHNET_ERR_ARG;
     if (!aligned16(k, sk) || !aligned16(v, sv) || !aligned16(q, sq)) return PHNET_ERR_ARG;
     const DropRng rng = keep ? DropRng{nullptr, 0, 0u} : phnet_make_rng(rng_state, rng_call, drop_p);
     AttnShape g{Lq, Lk, H, sq, sk, sv, so, 1.0f / sqrtf((float)D), keep ? keep_scale : (rng.thresh ? 1.0f / (1.0f - drop_p) : 1.0f)};
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3(H, (Lq + ROWS - 1) / ROWS), dim3(NT), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(H, (Lq + ROWS - 1) / ROWS, B), dim3(NT), 0, (hipStream_t)stream,
                        q, k, v, key_valid, keep, o, lse, g, rng);
     return phnet_launch_status();
 }
@@ -249,17 +265,17 @@ PHNET_API int phnet_attention_fwd(const float* q, const float* k, const float* v
 // dq [Lq][.] stride sdq, dk/dv [Lk][.] strides sdk/sdv are overwritten (rows of masked keys get zeros).
 PHNET_API int phnet_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* dout,
                                   const float* lse, const uint8_t* key_valid, const uint8_t* keep,
-                                  float* dq, float* dk, float* dv, int32_t Lq, int32_t Lk, int32_t H, int32_t E,
+                                  float* dq, float* dk, float* dv, int32_t B, int32_t Lq, int32_t Lk, int32_t H, int32_t E,
                                   int64_t sq, int64_t sk, int64_t sv, int64_t so, int64_t sdq, int64_t sdk, int64_t sdv,
                                   float keep_scale, const uint64_t* rng_state, uint64_t rng_call, float drop_p, void* stream)
 {
-    if (!attn_ok(Lq, Lk, H, E) || !q || !k || !v || !o || !dout || !lse || !dq || !dk || !dv || drop_p < 0.f || drop_p >= 1.f)
+    if (B < 1 || !attn_ok(Lq, Lk, H, E) || !q || !k || !v || !o || !dout || !lse || !dq || !dk || !dv || drop_p < 0.f || drop_p >= 1.f)
         return PHNET_ERR_ARG;
     if (!aligned16(k, sk) || !aligned16(v, sv) || !aligned16(q, sq) || !aligned16(dout, so) || !aligned16(o, so)) return PHNET_ERR_ARG;
     const DropRng rng = keep ? DropRng{nullptr, 0, 0u} : phnet_make_rng(rng_state, rng_call, drop_p);
     AttnShape g{Lq, Lk, H, sq, sk, sv, so, 1.0f / sqrtf((float)D), keep ? keep_scale : (rng.thresh ? 1.0f / (1.0f - drop_p) : 1.0f)};
     const int qt = (Lq + ROWS - 1) / ROWS, kt = (Lk + ROWS - 1) / ROWS;
-    hipLaunchKernelGGL(attn_bwd_kernel, dim3(H, qt + kt), dim3(NT), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(attn_bwd_kernel, dim3(H, qt + kt, B), dim3(NT), 0, (hipStream_t)stream,
                        q, k, v, o, dout, lse, key_valid, keep, dq, dk, dv, g, (long)sdq, (long)sdk, (long)sdv, qt, rng);
     return phnet_launch_status();
 }

@@ -80,6 +80,10 @@ __global__ __launch_bounds__(1024) void memory_tokens_kernel(const float* __rest
                                                              int N, int E, int L)
 {
     extern __shared__ float part[];                  // [groups][E]
+    {   // clip blockIdx.x of a batch
+        const size_t b = blockIdx.x;
+        feat += b * N * E; rows += b * L; tokens += b * (L + 1) * E; valid += b * (L + 1);
+    }
     const int e = threadIdx.x % E, grp = threadIdx.x / E, groups = blockDim.x / E;
     float s = 0.f;
     if (grp < groups)
@@ -328,14 +332,14 @@ PHNET_API int phnet_gelu_dropout_bwd(const float* dy, const float* x, float* dx,
     return phnet_launch_status();
 }
 
-// Memory tokens of one frame and stage (Router4OL.py:563-584).  feat [N][E] (E <= 1024), rows i64[L] (-1 padded),
-// tokens [L+1][E], valid u8[L+1].
+// Memory tokens of one frame and stage (Router4OL.py:563-584) for B clips.  feat [B][N][E] (E <= 1024), rows i64[B][L]
+// (-1 padded), tokens [B][L+1][E], valid u8[B][L+1].
 PHNET_API int phnet_memory_tokens(const float* feat, const int64_t* rows, float* tokens, uint8_t* valid,
-                                  int32_t N, int32_t E, int32_t L, void* stream)
+                                  int32_t B, int32_t N, int32_t E, int32_t L, void* stream)
 {
-    if (N < 1 || E < 1 || E > 1024 || L < 0 || !feat || (L && !rows) || !tokens || !valid) return PHNET_ERR_ARG;
+    if (B < 1 || N < 1 || E < 1 || E > 1024 || L < 0 || !feat || (L && !rows) || !tokens || !valid) return PHNET_ERR_ARG;
     const int groups = 1024 / E;
-    hipLaunchKernelGGL(memory_tokens_kernel, dim3(1), dim3(groups * E), (size_t)groups * E * sizeof(float), (hipStream_t)stream,
+    hipLaunchKernelGGL(memory_tokens_kernel, dim3(B), dim3(groups * E), (size_t)groups * E * sizeof(float), (hipStream_t)stream,
                        feat, (const long long*)rows, tokens, valid, N, E, L);
     return phnet_launch_status();
 }

@@ -408,7 +408,7 @@ class _Attention(torch.autograd.Function):
     Gradients are written straight into packed buffers of the same layout."""
 
     @staticmethod
-    def forward(ctx, heads, dropout_p, key_valid, q_in, kv_in):
+    def forward(ctx, heads, dropout_p, key_valid, q_in, kv_in, batch=1):
         e = q_in.shape[1] // 3 if kv_in is None else q_in.shape[1]
         q_in = q_in.contiguous()
         if kv_in is None:                      # self-attention, packed projection
@@ -418,9 +418,9 @@ class _Attention(torch.autograd.Function):
             q, k, v = q_in, kv_in[:, :e], kv_in[:, e:]
         rng = DropoutStream.site(q.device, dropout_p)          # attention-weight dropout drawn inside the kernels
         kvu8 = None if key_valid is None else key_valid.contiguous().view(torch.uint8)      # bool is one byte: no conversion launch
-        out, lse = K.attention_fwd(q, k, v, heads, kvu8, rng=rng)
+        out, lse = K.attention_fwd(q, k, v, heads, kvu8, rng=rng, batch=batch)
         ctx.save_for_backward(q_in, kv_in, out, lse, kvu8)
-        ctx.heads, ctx.rng, ctx.e = heads, rng, e
+        ctx.heads, ctx.rng, ctx.e, ctx.batch = heads, rng, e, batch
         return out
 
     @staticmethod
@@ -436,16 +436,16 @@ class _Attention(torch.autograd.Function):
             dkv_in = torch.empty_like(kv_in)
             q, k, v = q_in, kv_in[:, :e], kv_in[:, e:]
             dq, dk, dv = dq_in, dkv_in[:, :e], dkv_in[:, e:]
-        K.attention_bwd(q, k, v, out, dout.contiguous(), lse, ctx.heads, dq, dk, dv, kvu8, rng=ctx.rng)
-        return None, None, None, dq_in, dkv_in
+        K.attention_bwd(q, k, v, out, dout.contiguous(), lse, ctx.heads, dq, dk, dv, kvu8, rng=ctx.rng, batch=ctx.batch)
+        return None, None, None, dq_in, dkv_in, None
 
 
-def attention_packed(qkv: torch.Tensor, heads: int, dropout_p: float = 0.0) -> torch.Tensor:
-    """Self-attention on a packed [L,3E] projection."""
-    return _Attention.apply(heads, dropout_p, None, qkv, None)
+def attention_packed(qkv: torch.Tensor, heads: int, dropout_p: float = 0.0, batch: int = 1) -> torch.Tensor:
+    """Self-attention on a packed [B*L,3E] projection (B clips = contiguous row blocks, attention inside each block)."""
+    return _Attention.apply(heads, dropout_p, None, qkv, None, batch)
 
 
 def attention_cross(q: torch.Tensor, kv: torch.Tensor, heads: int, dropout_p: float = 0.0,
-                    key_valid: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Cross-attention: q [Lq,E], kv [M,2E] packed (k|v), optional bool key mask [M]."""
-    return _Attention.apply(heads, dropout_p, key_valid, q, kv)
+                    key_valid: Optional[torch.Tensor] = None, batch: int = 1) -> torch.Tensor:
+    """Cross-attention: q [B*Lq,E], kv [B*M,2E] packed (k|v), optional bool key mask [B*M] (per clip)."""
+    return _Attention.apply(heads, dropout_p, key_valid, q, kv, batch)

@@ -73,21 +73,24 @@ class GraphedTrainStep:
 
 class GraphedInference:
     """Eval forward of a fixed-length clip (backbone + lane head + fused decode/NMS for every frame) captured in one
-    hipGraph; `__call__` copies the frames in, replays, and returns the device-resident (kept_rows, num, anchors)."""
+    hipGraph; `__call__` copies the frames in, replays, and returns the device-resident (kept_rows, num, anchors).
+    frames [T,3,H,W]: one clip (RouterOL.infer_device); frames [B,T,3,H,W]: B clips per replay with the lane head
+    batched across the clips (RouterOL.infer_clips_device)."""
 
     def __init__(self, model: torch.nn.Module, frames: torch.Tensor, warmup: int = 2):
         self.model = model.eval()
         self.frames = frames.clone()
+        infer = model.infer_clips_device if frames.dim() == 5 else model.infer_device
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side), torch.no_grad():
             for _ in range(warmup):
-                model.infer_device(self.frames)
+                infer(self.frames)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(self.graph):
-            self.out = model.infer_device(self.frames)
+            self.out = infer(self.frames)
         torch.cuda.synchronize()
 
     def __call__(self, frames: torch.Tensor):

@@ -550,38 +550,42 @@ def _rng_args(rng):
     return _ptr(state), int(call), float(p)
 
 
-def attention_fwd(q, k, v, heads: int, key_valid=None, keep=None, keep_scale: float = 1.0, rng=None):
+def attention_fwd(q, k, v, heads: int, key_valid=None, keep=None, keep_scale: float = 1.0, rng=None, batch: int = 1):
     """q [Lq,E], k/v [Lk,E] (any row stride, unit column stride) -> (o [Lq,E], lse [H,Lq]).  Dropout of the attention
     weights: explicit `keep` u8[H,Lq,Lk] (+ keep_scale), or `rng` for the in-kernel counter-based mask."""
-    lq, e = q.shape
-    lk = k.shape[0]
-    assert q.stride(1) == 1 and k.stride(1) == 1 and v.stride(1) == 1
-    out = torch.empty((lq, e), dtype=torch.float32, device=q.device)
-    lse = torch.empty((heads, lq), dtype=torch.float32, device=q.device)
-    check(lib().phnet_attention_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(key_valid), _ptr(keep), _ptr(out), _ptr(lse), lq, lk, heads, e,
+    e = q.shape[1]
+    lq, lk = q.shape[0] // batch, k.shape[0] // batch          # `batch` clips: contiguous row blocks of q and of k / v
+    assert q.stride(1) == 1 and k.stride(1) == 1 and v.stride(1) == 1 and q.shape[0] == lq * batch and k.shape[0] == lk * batch
+    out = torch.empty((lq * batch, e), dtype=torch.float32, device=q.device)
+    lse = torch.empty((batch * heads, lq), dtype=torch.float32, device=q.device)
+    check(lib().phnet_attention_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(key_valid), _ptr(keep), _ptr(out), _ptr(lse), batch, lq, lk, heads, e,
                                     q.stride(0), k.stride(0), v.stride(0), out.stride(0), float(keep_scale), *_rng_args(rng), _stream()),
           "phnet_attention_fwd")
     return out, lse
 
 
-def attention_bwd(q, k, v, o, dout, lse, heads: int, dq, dk, dv, key_valid=None, keep=None, keep_scale: float = 1.0, rng=None):
+def attention_bwd(q, k, v, o, dout, lse, heads: int, dq, dk, dv, key_valid=None, keep=None, keep_scale: float = 1.0, rng=None,
+                  batch: int = 1):
     """Writes dq/dk/dv (views with arbitrary row stride)."""
-    lq, e = q.shape
-    lk = k.shape[0]
+    e = q.shape[1]
+    lq, lk = q.shape[0] // batch, k.shape[0] // batch
     check(lib().phnet_attention_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(dout), _ptr(lse), _ptr(key_valid), _ptr(keep),
-                                    _ptr(dq), _ptr(dk), _ptr(dv), lq, lk, heads, e, q.stride(0), k.stride(0), v.stride(0),
+                                    _ptr(dq), _ptr(dk), _ptr(dv), batch, lq, lk, heads, e, q.stride(0), k.stride(0), v.stride(0),
                                     o.stride(0), dq.stride(0), dk.stride(0), dv.stride(0), float(keep_scale), *_rng_args(rng),
                                     _stream()), "phnet_attention_bwd")
 
 
 def memory_tokens(feat, rows):
-    """feat [N,E] (or [N,1,E]), rows i64[L] (-1 padded) -> (tokens [L+1,1,E], valid bool[L+1]) in one launch."""
+    """feat [N,E] / [N,1,E] with rows i64[L] (-1 padded) -> (tokens [L+1,1,E], valid bool[L+1]); or a batch of clips:
+    feat [B,N,E] with rows i64[B,L] -> (tokens [B,L+1,E], valid bool[B,L+1]).  One launch."""
     _req(feat, name="feat"); _req(rows, torch.int64, "rows")
-    n, e = feat.shape[0], feat.shape[-1]
-    l = rows.numel()
-    tokens = torch.empty((l + 1, 1, e), dtype=torch.float32, device=feat.device)
-    valid = torch.empty((l + 1,), dtype=torch.bool, device=feat.device)
-    check(lib().phnet_memory_tokens(_ptr(feat), _ptr(rows), _ptr(tokens), _ptr(valid), n, e, l, _stream()), "phnet_memory_tokens")
+    batched = rows.dim() == 2
+    b = rows.shape[0] if batched else 1
+    l, e = rows.shape[-1], feat.shape[-1]
+    n = feat.numel() // (b * e)
+    tokens = torch.empty((b, l + 1, e) if batched else (l + 1, 1, e), dtype=torch.float32, device=feat.device)
+    valid = torch.empty((b, l + 1) if batched else (l + 1,), dtype=torch.bool, device=feat.device)
+    check(lib().phnet_memory_tokens(_ptr(feat), _ptr(rows), _ptr(tokens), _ptr(valid), b, n, e, l, _stream()), "phnet_memory_tokens")
     return tokens, valid
 
 
@@ -612,7 +616,8 @@ def gate_tail_bwd(dout, out, h, w, need_dh: bool = True, dw: Optional[torch.Tens
 def blend_priors(gate, a, b, idx):
     """gate [N] (or [1,N,1]), a/b [1,N,W], idx i64[P] -> (priors [1,N,W], on_map [1,N,P])."""
     _req(gate, name="gate"); _req(a, name="lines_a"); _req(b, name="lines_b"); _req(idx, torch.int64, "idx")
-    n, w = a.shape[-2], a.shape[-1]
+    w = a.shape[-1]
+    n = a.numel() // w                                   # all leading dimensions are rows (frames / clips x anchors)
     p = idx.numel()
     priors = torch.empty_like(a)
     on_map = torch.empty(a.shape[:-1] + (p,), dtype=torch.float32, device=a.device)

@@ -242,6 +242,39 @@ class DetNetV2(nn.Module):
                                                 r["lines_b"].detach().contiguous(), self.sample_x_indexs)
         return {"predictions_fir": out_a, "predictions_sec": out_b}, attn_feats, gates
 
+    def forward_clips(self, x, last_cuts=None, stage0=None):
+        """Eval-time twin of forward() for the SAME frame index of B independent clips: x = (P3, P4, P5) [B,h,w,C];
+        last_cuts = list over remembered frames of per-stage (tokens [B,L+1,E], valid [B,L+1]); stage0 = stage_front results
+        [B,...] of stage 0.  Every head kernel sees B*N rows; attention and the memory tokens stay inside each clip.
+        Returns ({"predictions_fir": [...], "predictions_sec": [...]} with [B,N,6+S] entries, attn feats [B,N,2C], gates [B,N,1])."""
+        levels = list(x)[::-1]
+        last_cuts = last_cuts or []
+        B, N = levels[0].shape[0], self.num_priors
+        priors = self.priors.unsqueeze(0).expand(B, -1, -1)
+        on_map = self.priors_on_featmap.unsqueeze(0).expand(B, -1, -1).contiguous()
+        pro_feat = self.pro_embedding.weight.unsqueeze(0).expand(B, -1, -1)
+        pos = self.PositionEmbedding.embed.weight.unsqueeze(0).expand(B, -1, -1)
+        out_a, out_b, attn_feats, gates = [], [], [], []
+        from phnet_amd import hip_ops as K
+        for stage in range(self.refine_layers):
+            front = stage0 if (stage == 0 and stage0 is not None) else self.stage_front(levels[stage], stage, priors, on_map, pro_feat)
+            local = front["local"]
+            attn = torch.cat([local, pos], dim=-1)                                   # [B,N,2C]
+            if len(last_cuts):
+                mem = torch.cat([fr[stage][0] for fr in last_cuts], dim=1)           # [B,M,2C]
+                valid = torch.cat([fr[stage][1] for fr in last_cuts], dim=1)         # [B,M]
+                feat = self.transformer_Dec(tgt=attn.reshape(B * N, -1), memory=mem.reshape(-1, mem.shape[-1]),
+                                            memory_key_valid=valid.reshape(-1), batch=B)
+            else:
+                feat = attn
+            pred_b, lines_b = self._branch(feat.reshape(B, N, -1), priors, True)
+            pro_feat = local.detach()
+            out_a.append(front["pred_a"]); out_b.append(pred_b); attn_feats.append(attn); gates.append(front["gate"])
+            if stage != self.refine_layers - 1:
+                priors, on_map = K.blend_priors(front["gate"].detach().contiguous(), front["lines_a"].detach().contiguous(),
+                                                lines_b.detach().contiguous(), self.sample_x_indexs)
+        return {"predictions_fir": out_a, "predictions_sec": out_b}, attn_feats, gates
+
     # ---- decode ---------------------------------------------------------------------------------------------------
     def predictions_to_pred(self, predictions, ori_img_h=None, cut_height=0):
         """Kept lanes [k,6+S] (length already in strips) -> list of Lane.  Host-side, float64 like the reference
@@ -335,6 +368,33 @@ class RouterOL(nn.Module):
                 last_cuts.pop(0)
         self._begin_clip()
         return torch.stack(rows), torch.stack(nums), torch.stack(anchors)
+
+    def infer_clips_device(self, frames: torch.Tensor):
+        """Eval forward of B clips at once, frames [B,T,3,H,W]: the per-frame chain is serial only INSIDE a clip, so frame t of
+        all clips runs through the lane head together (B*N rows per kernel instead of N - the head is launch-bound at N = 240).
+        No host synchronisation (hipGraph-capturable).  Returns (kept_rows [B,T,max_lanes,6+S], num [B,T], anchors [B,T,max_lanes])."""
+        from phnet_amd import hip_ops as K
+        B, T = frames.shape[:2]
+        self._begin_clip()
+        feats = self.backbone(frames.transpose(0, 1).reshape(T * B, *frames.shape[2:]))      # frame-major: [t*B + b]
+        det = self.detNet
+        n0 = feats[-1].shape[0]
+        front0 = det.stage_front(feats[-1], 0, det.priors.unsqueeze(0).expand(n0, -1, -1),
+                                 det.priors_on_featmap.unsqueeze(0).expand(n0, -1, -1).contiguous(),
+                                 det.pro_embedding.weight.unsqueeze(0).expand(n0, -1, -1))
+        last_cuts, rows, nums, anchors = [], [], [], []
+        for t in range(T):
+            cur = tuple(f[t * B:(t + 1) * B] for f in feats)
+            outputs, cur_cut, gates = det.forward_clips(cur, last_cuts, {k: v[t * B:(t + 1) * B] for k, v in front0.items()})
+            d = torch.stack(gates, dim=0).mean(dim=0)
+            lines = outputs["predictions_sec"][-1] * d + outputs["predictions_fir"][-1] * (1 - d)
+            dec = det.decode_device(lines)                                                    # batched over the B clips
+            rows.append(dec["kept_rows"]); nums.append(dec["num"]); anchors.append(dec["anchors"])
+            last_cuts.append([K.memory_tokens(feat.detach().contiguous(), dec["anchors_sorted"].contiguous()) for feat in cur_cut])
+            if t >= self.save_freq_max:
+                last_cuts.pop(0)
+        self._begin_clip()
+        return torch.stack(rows, dim=1), torch.stack(nums, dim=1), torch.stack(anchors, dim=1)
 
     def lanes_from_device(self, kept_rows: torch.Tensor, nums: torch.Tensor):
         """One device->host copy per clip, then the host-side Lane construction (Router4OL.py:394-435)."""

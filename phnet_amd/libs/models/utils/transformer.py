@@ -9,18 +9,19 @@ import torch.nn as nn
 from phnet_amd import functional as PF
 
 
-def _attention(mha: nn.MultiheadAttention, q_in: torch.Tensor, kv_in: torch.Tensor, training: bool, key_valid=None) -> torch.Tensor:
-    """q_in [L,E], kv_in [M,E] (batch 1) -> [L,E]; key_valid bool[M] masks padded memory slots."""
+def _attention(mha: nn.MultiheadAttention, q_in: torch.Tensor, kv_in: torch.Tensor, training: bool, key_valid=None,
+               batch: int = 1) -> torch.Tensor:
+    """q_in [B*L,E], kv_in [B*M,E] (B clips as contiguous row blocks) -> [B*L,E]; key_valid bool[B*M] masks padded memory slots."""
     e, h = mha.embed_dim, mha.num_heads
     w, b = mha.in_proj_weight, mha.in_proj_bias
     p_drop = mha.dropout if training else 0.0
     if q_in is kv_in:
         qkv = PF.linear(q_in, w, b)                       # self-attention: one [L,3E] projection on the whole in_proj
-        out = PF.attention_packed(qkv, h, p_drop)
+        out = PF.attention_packed(qkv, h, p_drop, batch)
     else:
         q = PF.linear(q_in, w, b, rows=(0, e))
         kv = PF.linear(kv_in, w, b, rows=(e, 3 * e))
-        out = PF.attention_cross(q, kv, h, p_drop, key_valid)
+        out = PF.attention_cross(q, kv, h, p_drop, key_valid, batch)
     return PF.linear(out, mha.out_proj.weight, mha.out_proj.bias)
 
 
@@ -38,16 +39,16 @@ class TransformerDecoderLayer(nn.Module):
         self.dropout1, self.dropout2, self.dropout3 = nn.Dropout(dropout), nn.Dropout(dropout), nn.Dropout(dropout)
         self.normalize_before = normalize_before
 
-    def forward(self, tgt: torch.Tensor, memory: torch.Tensor, memory_key_valid=None, h=None, next_norm=None):
+    def forward(self, tgt: torch.Tensor, memory: torch.Tensor, memory_key_valid=None, h=None, next_norm=None, batch: int = 1):
         """tgt [L,E], memory [M,E], memory_key_valid bool[M] or None.  h = norm1(tgt) if the caller already has it.
         Every residual update is fused with the LayerNorm that follows it (norm2, norm3, and `next_norm` = the next
         layer's norm1 or the decoder's final norm).  Returns (tgt_out, next_norm(tgt_out) or None)."""
         p = lambda d: d.p if self.training else 0.0                                  # noqa: E731
         if h is None:
             h = PF.layer_norm(tgt, self.norm1.weight, self.norm1.bias, eps=self.norm1.eps)
-        tgt, h = PF.dropout_add_ln(tgt, _attention(self.self_attn, h, h, self.training),
+        tgt, h = PF.dropout_add_ln(tgt, _attention(self.self_attn, h, h, self.training, batch=batch),
                                    self.norm2.weight, self.norm2.bias, p(self.dropout1), self.norm2.eps)
-        tgt, h = PF.dropout_add_ln(tgt, _attention(self.multihead_attn, h, memory, self.training, memory_key_valid),
+        tgt, h = PF.dropout_add_ln(tgt, _attention(self.multihead_attn, h, memory, self.training, memory_key_valid, batch),
                                    self.norm3.weight, self.norm3.bias, p(self.dropout2), self.norm3.eps)
         h = PF.gelu_dropout(PF.linear(h, self.linear1.weight, self.linear1.bias), p(self.dropout))
         f = PF.linear(h, self.linear2.weight, self.linear2.bias)
@@ -64,12 +65,13 @@ class TransformerDecoder(nn.Module):
         self.norm = copy.deepcopy(norm)
         self.return_intermediate = return_intermediate
 
-    def forward(self, tgt: torch.Tensor, memory: torch.Tensor, memory_key_valid=None) -> torch.Tensor:
-        """tgt [L,1,E] or [L,E]; memory [M,1,E] or [M,E]; memory_key_valid bool[M]; returns the same rank as tgt."""
+    def forward(self, tgt: torch.Tensor, memory: torch.Tensor, memory_key_valid=None, batch: int = 1) -> torch.Tensor:
+        """tgt [L,1,E] or [L,E]; memory [M,1,E] or [M,E]; memory_key_valid bool[M]; returns the same rank as tgt.
+        batch = B: tgt [B*L,E], memory [B*M,E], mask [B*M] hold B clips as contiguous row blocks."""
         shape = tgt.shape
-        x, mem = tgt.reshape(shape[0], shape[-1]), memory.reshape(memory.shape[0], memory.shape[-1])
+        x, mem = tgt.reshape(-1, shape[-1]), memory.reshape(-1, memory.shape[-1])
         h = None
         for i, layer in enumerate(self.layers):
             nxt = self.layers[i + 1].norm1 if i + 1 < len(self.layers) else self.norm
-            x, h = layer(x, mem, memory_key_valid, h=h, next_norm=nxt)
+            x, h = layer(x, mem, memory_key_valid, h=h, next_norm=nxt, batch=batch)
         return (h if self.norm is not None else x).reshape(shape)

@@ -367,6 +367,32 @@ def test_stage0_batched_over_frames_equals_per_frame_stage0():
     _close(a[0], b[0], 1e-4, "kept rows")
 
 
+def test_inference_batched_over_clips_equals_clip_by_clip():
+    """RouterOL.infer_clips_device: B clips through the lane head together (B*N rows per kernel, attention and memory tokens
+    per clip) == the same clips one by one: kept anchors / counts identical, kept rows to fp32 re-association."""
+    from phnet_amd.graphed import GraphedInference
+    g = O.Geometry(img_h=64, img_w=160, arch="resnet18", conf_threshold=0.3)
+    T, B = 4, 3
+    model = _build(g).eval()
+    model.detNet.cfg.test_parameters.conf_threshold = 0.3          # low threshold: lanes are actually kept, the memory is used
+    clips = torch.stack([synth.make_clip(g, T, seed=40 + b) for b in range(B)]).cuda()
+    with torch.no_grad():
+        rows_b, nums_b, anch_b = model.infer_clips_device(clips)
+        singles = [model.infer_device(clips[b]) for b in range(B)]
+    assert int(nums_b.sum()) > 0
+    for b in range(B):
+        rows_s, nums_s, anch_s = singles[b]
+        assert torch.equal(nums_b[b], nums_s)
+        for t in range(T):
+            k = int(nums_s[t])
+            assert torch.equal(anch_b[b, t, :k], anch_s[t, :k])
+            _close(rows_b[b, t, :k], rows_s[t, :k], 2e-4, f"kept rows clip {b} frame {t}")
+    graph = GraphedInference(model, clips)
+    rows_g, nums_g, anch_g = graph(clips)
+    assert torch.equal(nums_g, nums_b) and torch.equal(anch_g, anch_b)
+    _close(rows_g, rows_b, 1e-5, "graph replay")
+
+
 def test_arena_direct_accumulation_equals_autograd_accumulation():
     """Gradients accumulated by the HIP kernels straight into the flat arena == autograd's own accumulation."""
     from phnet_amd.arena import GradArena

@@ -22,6 +22,21 @@ def main(clips=32, T=5, H=320, W=800, arch="resnet34"):
     host = model.lanes_from_device(rows, nums)           # one D2H + Lane objects for the last clip (per-clip host work)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # B clips per replay, lane head batched across the clips
+    batched = {}
+    for B in (4, 8):
+        big = torch.stack([batch[i % 4] for i in range(B)])
+        gb = GraphedInference(model, big)
+        for _ in range(2):
+            gb(big)
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
+        for _ in range(clips // B):
+            rb, nb, ab = gb(big)
+        torch.cuda.synchronize()
+        dtb = time.perf_counter() - tb
+        batched[f"clips_per_s_batched_{B}"] = round((clips // B) * B / dtb, 2)
+        del gb
     with torch.no_grad():
         t1 = time.perf_counter()
         for i in range(4):
@@ -30,7 +45,8 @@ def main(clips=32, T=5, H=320, W=800, arch="resnet34"):
         eager = (time.perf_counter() - t1) / 4
     print(json.dumps({"workload": f"{clips} clips x {T} frames 3x{H}x{W}, {arch}, eval, hipGraph", "clips_per_s": round(clips / dt, 2),
                       "frames_per_s": round(clips * T / dt, 1), "ms_per_clip_graph": round(dt / clips * 1e3, 2),
-                      "ms_per_clip_eager_sync_free": round(eager * 1e3, 2), "lanes_last_clip": [len(x) for x in host["lane_lines"]]}))
+                      "ms_per_clip_eager_sync_free": round(eager * 1e3, 2), "lanes_last_clip": [len(x) for x in host["lane_lines"]],
+                      **batched, "frames_per_s_batched_8": round(batched["clips_per_s_batched_8"] * T, 1)}))
 
 if __name__ == "__main__":
     main()
