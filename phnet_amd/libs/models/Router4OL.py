@@ -396,6 +396,48 @@ class RouterOL(nn.Module):
         self._begin_clip()
         return torch.stack(rows, dim=1), torch.stack(nums, dim=1), torch.stack(anchors, dim=1)
 
+    def forward_clips_train(self, frames: torch.Tensor, lanes: torch.Tensor):
+        """Training forward of B clips in one pass: frames [B,T,3,H,W], lanes [B,T,max_lanes,6+S] -> summed loss of all
+        clips.  Frame t of every clip goes through the lane head together (B*N rows per kernel); attention, memory tokens,
+        label assignment and the criterion stay per clip.  BatchNorm statistics are taken over all B*T frames - exactly what
+        the reference computes with B data-parallel ranks and SyncBatchNorm (trainOL.py:141): the clips of a step are
+        "virtual ranks" on one GPU."""
+        from phnet_amd import hip_ops as K
+        B, T = frames.shape[:2]
+        self._begin_clip()
+        PF.DropoutStream.begin_step(frames.device)
+        feats = self.backbone(frames.transpose(0, 1).reshape(T * B, *frames.shape[2:]))      # frame-major: [t*B + b]
+        det = self.detNet
+        det.priors, det.priors_on_featmap = det.generate_priors_from_embeddings()
+        n0 = feats[-1].shape[0]
+        front0 = det.stage_front(feats[-1], 0, det.priors.unsqueeze(0).expand(n0, -1, -1),
+                                 det.priors_on_featmap.unsqueeze(0).expand(n0, -1, -1).contiguous(),
+                                 det.pro_embedding.weight.unsqueeze(0).expand(n0, -1, -1))
+        front0 = {k: v.split(B, dim=0) for k, v in front0.items()}                           # per frame index: [B,...] (one cat backward)
+        levels = [f.split(B, dim=0) for f in feats]
+        last_cuts, total_loss = [], 0.0
+        for t in range(T):
+            cur = tuple(lv[t] for lv in levels)
+            outputs, cur_cut, gates = det.forward_clips(cur, last_cuts, {k: v[t] for k, v in front0.items()})
+            matched_all = []
+            per_clip = {k: [p.split(1, dim=0) for p in v] for k, v in outputs.items()}       # split: one cat in the backward
+            gate_clip = [gt.split(1, dim=0) for gt in gates]
+            for b in range(B):                                                               # criterion per clip (2 launches each)
+                out_b = {k: [ps[b] for ps in v] for k, v in per_clip.items()}
+                matched, loss_b = self.criterion(out_b, lanes[b, t:t + 1], [gs[b] for gs in gate_clip])
+                total_loss = total_loss + loss_b
+                matched_all.append(matched)
+            with torch.no_grad():
+                tokens = []
+                for s_i, feat in enumerate(cur_cut):
+                    rows = torch.stack([matched_all[b][s_i] for b in range(B)])              # [B,L] matched anchors, -1 padded
+                    tokens.append(K.memory_tokens(feat.detach().contiguous(), rows))
+                last_cuts.append(tokens)
+                if t >= self.save_freq_max:
+                    last_cuts.pop(0)
+        self._begin_clip()
+        return total_loss
+
     def lanes_from_device(self, kept_rows: torch.Tensor, nums: torch.Tensor):
         """One device->host copy per clip, then the host-side Lane construction (Router4OL.py:394-435)."""
         rows, n = kept_rows.cpu(), nums.cpu().tolist()
@@ -405,6 +447,12 @@ class RouterOL(nn.Module):
         frame, lanes = inputs.values()
         if not frame.is_cuda:
             raise RuntimeError("phnet_amd runs on the GPU only: move the model and the clip to cuda")
+        if frame.dim() == 5:                                   # [B,T,3,H,W]: several clips per step, head batched across clips
+            if self.training:
+                return self.forward_clips_train(frame, lanes)
+            rows, nums, _ = self.infer_clips_device(frame)
+            B = frame.shape[0]
+            return [self.lanes_from_device(rows[b], nums[b]) for b in range(B)]
         if not self.training and self.sync_free_eval:
             rows, nums, _ = self.infer_device(frame)
             return self.lanes_from_device(rows, nums)

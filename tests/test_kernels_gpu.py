@@ -506,7 +506,7 @@ def test_dropout_add_layernorm_fused(ops, L):
     close(dx2[kept], (dres2 / (1 - p))[kept], 1e-5)
 
 
-@pytest.mark.parametrize("M,K,N", [(240, 128, 384), (240, 192, 44), (240, 256, 128), (37, 64, 64), (256, 2304, 64)])
+@pytest.mark.parametrize("M,K,N", [(240, 128, 384), (240, 192, 44), (240, 256, 128), (37, 64, 64), (256, 2304, 64), (240, 2304, 576)])
 def test_linear_backward_fused_launch(ops, M, K, N):
     """dx, dW (accumulated) and dbias of a few-rows Linear layer from ONE launch vs fp64 torch."""
     assert ops.linear_bwd_fusable(M, K, N)
