@@ -37,6 +37,10 @@ def parse():
     ap.add_argument("--frames", type=int, default=5)
     ap.add_argument("--height", type=int, default=320)
     ap.add_argument("--width", type=int, default=800)
+    ap.add_argument("--clips-per-gpu", type=int, default=1,
+                    help="clips per GPU and step (default 1 = BASELINE.json configs[1], the reference's train_batch).  B > 1 runs "
+                         "the lane head batched across the clips with joint BatchNorm statistics = the reference's DDP + "
+                         "SyncBatchNorm over B virtual ranks on one GPU; a different workload, reported as such")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-clips", type=int, default=6)
     ap.add_argument("--no-kernel-timer", action="store_true")
@@ -116,10 +120,15 @@ def main():
     T = args.frames
     lanes = make_targets(args.height, args.width, T).to(dev)
     clips = [make_clip(args.height, args.width, T, seed=3407 + rank + 17 * i).to(dev) for i in range(4)]
+    CB = args.clips_per_gpu
+    if CB > 1:                                      # [B,T,3,H,W] inputs: RouterOL batches the head across the clips
+        lanes = torch.stack([lanes] * CB)
+        clips = [torch.stack([make_clip(args.height, args.width, T, seed=3407 + rank + 17 * i + 101 * b) for b in range(CB)]).to(dev)
+                 for i in range(2)]
 
     def step(i):
         arena.zero()
-        loss = net({"frame": clips[i % len(clips)], "lanes": lanes}) / T
+        loss = net({"frame": clips[i % len(clips)], "lanes": lanes}) / (T * CB)
         loss.backward()
         if world > 1:
             parallel.allreduce_flat_(arena.flat, chunks=4)      # RCCL all-reduce (mean) of all gradients over xGMI
@@ -131,7 +140,7 @@ def main():
         from phnet_amd.graphed import GraphedTrainStep
         try:
             between = (lambda: parallel.allreduce_flat_(arena.flat, chunks=4)) if world > 1 else None
-            graphed = GraphedTrainStep(model, opt, clips[0], lanes, loss_divisor=T, warmup=2, arena=arena, between=between)
+            graphed = GraphedTrainStep(model, opt, clips[0], lanes, loss_divisor=T * CB, warmup=2, arena=arena, between=between)
             print("[bench] training step captured in a hipGraph", file=sys.stderr, flush=True)
         except Exception as e:                                       # noqa: BLE001
             print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr, flush=True)
@@ -243,11 +252,11 @@ def main():
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args)
-        out = {"metric": "clips/s (5x3x320x800) fwd+bwd", "value": round(world * args.steps / dt, 4), "unit": "clips/s",
+        out = {"metric": "clips/s (5x3x320x800) fwd+bwd", "value": round(world * CB * args.steps / dt, 4), "unit": "clips/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": f"{T}-frame clip 3x{args.height}x{args.width}, {args.arch} + router + lane head, fwd+bwd+AdamW, "
-                                      f"1 clip/GPU/step, random-init weights", "parallelism": f"dp{world}",
+                                      f"{CB} clip{'s' if CB > 1 else ''}/GPU/step, random-init weights", "parallelism": f"dp{world}",
                           "timed_region": "grad-arena memset + forward + loss + backward (+ flat RCCL all-reduce when N>1) + AdamW step",
                           "launch": ("hipGraph replay of the whole step" if world == 1 else "hipGraph(fwd+bwd) -> RCCL all-reduce -> hipGraph(AdamW)")
                                     if graphed is not None else "eager"},
