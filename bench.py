@@ -41,6 +41,9 @@ def parse():
                     help="clips per GPU and step (default 1 = BASELINE.json configs[1], the reference's train_batch).  B > 1 runs "
                          "the lane head batched across the clips with joint BatchNorm statistics = the reference's DDP + "
                          "SyncBatchNorm over B virtual ranks on one GPU; a different workload, reported as such")
+    ap.add_argument("--batched-extra", type=int, default=8,
+                    help="N = 1 only: after the headline measurement, also time B clips per GPU and step in a child process and "
+                         "report it under the extra key 'batched' (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-clips", type=int, default=6)
     ap.add_argument("--no-kernel-timer", action="store_true")
@@ -78,6 +81,27 @@ def cpu_baseline(args):
     return {"value": args.cpu_clips / dt, "unit": "clips/s", "cores": cores, "kind": "port",
             "sample": f"{args.cpu_clips} clips of {args.frames}x3x{args.height}x{args.width} fwd+bwd (no optimizer, no warm-up), "
                       f"oracle/phnet_cpu.py on torch CPU fp32, {dt:.1f} s"}
+
+
+def batched_extra(args):
+    """Not the headline: the same step with B clips per GPU (lane head batched across the clips, joint BatchNorm statistics =
+    the reference's DDP + SyncBatchNorm over B virtual ranks), timed in a child process so that it cannot disturb the run above."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--clips-per-gpu", str(args.batched_extra), "--no-cpu-baseline", "--no-kernel-timer",
+           "--batched-extra", "0", "--steps", "6", "--warmup", "2", "--arch", args.arch, "--frames", str(args.frames),
+           "--height", str(args.height), "--width", str(args.width)]
+    try:
+        print(f"[bench] extra: {args.batched_extra} clips per GPU and step (child process)", file=sys.stderr, flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+        d = json.loads(line)
+        return {"clips_per_gpu": args.batched_extra, "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
+                "note": "same model and step with B clips per GPU and step: the per-frame chain is serial only inside a clip, so the "
+                        "lane head runs B*240 rows per kernel; BatchNorm statistics over all B*T frames = the reference's DDP + "
+                        "SyncBatchNorm over B ranks.  A different workload than the headline (1 clip/GPU/step)."}
+    except Exception as e:                                             # noqa: BLE001
+        print(f"[bench] extra batched measurement failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+        return None
 
 
 def main():
@@ -252,6 +276,9 @@ def main():
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args)
+        batched = None
+        if world == 1 and CB == 1 and args.batched_extra > 1 and use_graph:
+            batched = batched_extra(args)
         out = {"metric": "clips/s (5x3x320x800) fwd+bwd", "value": round(world * CB * args.steps / dt, 4), "unit": "clips/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -261,6 +288,8 @@ def main():
                           "launch": ("hipGraph replay of the whole step" if world == 1 else "hipGraph(fwd+bwd) -> RCCL all-reduce -> hipGraph(AdamW)")
                                     if graphed is not None else "eager"},
                "loss": round(float(loss.item()), 4), "roofline": roof, "cpu_baseline": cpu}
+        if batched is not None:
+            out["batched"] = batched
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
