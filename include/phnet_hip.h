@@ -82,6 +82,10 @@ int phnet_tune_force_conv_tile(int32_t bm, int32_t bn, int32_t splits);
 int phnet_tune_force_k_tile(int32_t k_tile);   /* 0 = heuristic, else 16 | 32 | 64; -1 / -2: uniform-tap kernel variant off / on */
 int phnet_tune_wgrad(int32_t allow_bm128, int32_t target_blocks);   /* wgrad tile / split-K policy; bit 1 of the first
                                                                         argument disables the few-rows Linear kernel */
+/* arithmetic of conv2d fwd / dgrad / wgrad (process-global): 0 = f32-input MFMA (default, what every published number
+ * uses), 1 = split-bf16: operands split in registers into two bf16 terms, 3 bf16 MFMAs per product, f32 accumulation
+ * (~2^-16 relative per product). */
+int phnet_tune_mma(int32_t mode);
 uint64_t phnet_conv2d_wgrad_workspace(int32_t N, int32_t Hi, int32_t Wi, int32_t Ci, int32_t Co,
                                       int32_t R, int32_t S, int32_t stride, int32_t pad);
 /* dbias (optional, [Co]) = sum of dy over all pixels = the bias gradient, produced by the same launch. */

@@ -38,7 +38,7 @@ struct RowCoord { int base, iy0, ix0; bool ok; };
 // (block, nblocks, split) are what blockIdx.x / gridDim.x / blockIdx.z are for the plain kernel below.
 // AMASK: the A operand is a gradient that still has to pass a ReLU - element (row, k) counts only where amask (the saved
 // forward output of that ReLU, same layout as X) is positive; applied when the tile is written to LDS.
-template <int BM, int BN, bool B_DGRAD, int BKT, bool UNI, bool AMASK = false>
+template <int BM, int BN, bool B_DGRAD, int BKT, bool UNI, bool AMASK = false, int MMA = 0>
 __device__ __forceinline__ void igemm_tile(
     const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ bias,
     const float* __restrict__ addend, float* __restrict__ out, const ConvShape& g, int relu,
@@ -237,7 +237,7 @@ __device__ __forceinline__ void igemm_tile(
             read_kcontig<FM, A_PITCH>(As + buf * A_FLOATS + wm * A_PITCH, lane, ks, a);
             if (!B_DGRAD) read_kcontig<FN, B_PITCH>(Bs + buf * B_FLOATS + wn * B_PITCH, lane, ks, b);
             else read_kstrided<FN, B_PITCH>(Bs + buf * B_FLOATS + wn, lane, ks, b);
-            mma_step<FM, FN>(a, b, acc);
+            mma_any<MMA, FM, FN>(a, b, acc);
         }
     };
 
@@ -276,13 +276,13 @@ __device__ __forceinline__ void igemm_tile(
     }
 }
 
-template <int BM, int BN, bool B_DGRAD, int BKT, bool UNI>
+template <int BM, int BN, bool B_DGRAD, int BKT, bool UNI, int MMA = 0>
 __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(
     const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ bias,
     const float* __restrict__ addend, float* __restrict__ out, ConvShape g, int relu)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    igemm_tile<BM, BN, B_DGRAD, BKT, UNI>(X, W, bias, addend, out, g, relu, lds, blockIdx.x, gridDim.x, blockIdx.z);
+    igemm_tile<BM, BN, B_DGRAD, BKT, UNI, false, MMA>(X, W, bias, addend, out, g, relu, lds, blockIdx.x, gridDim.x, blockIdx.z);
 }
 
 // out[i] = sum_z part[z][i] (+bias[i % ncols]) (relu)
@@ -314,7 +314,7 @@ struct WgradShape {
 
 // out: dW itself when g.splits == 1 (written or accumulated in the epilogue) else the split-K partial buffer
 // [splits][Co*NC + Co] (the trailing Co floats of every split hold its bias-gradient partial).
-template <int BM, int BN>
+template <int BM, int BN, int MMA = 0>
 __global__ __launch_bounds__(THREADS) void conv_wgrad_kernel(
     const float* __restrict__ dY, const float* __restrict__ X, float* __restrict__ out, float* __restrict__ dbias,
     WgradShape g, int want_bias, int accumulate)
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(THREADS) void conv_wgrad_kernel(
             float a[FM][8], b[FN][8];
             read_kstrided<FM, A_PITCH>(As + buf * A_FLOATS + wm, lane, 0, a);
             read_kstrided<FN, B_PITCH>(Bs + buf * B_FLOATS + wn, lane, 0, b);
-            mma_step<FM, FN>(a, b, acc);
+            mma_any<MMA, FM, FN>(a, b, acc);
             __builtin_amdgcn_sched_barrier(0);           // the LDS fill (and its wait for the loads) stays behind the MFMAs
             store_lds(buf ^ 1);
             __syncthreads();
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(THREADS) void conv_wgrad_kernel(
 // the result goes (or accumulates) straight into the gradient arena.  The bias gradient is the column sum of the staged
 // dY tile.
 constexpr int SMALLP_MAX = 256;
-template <int BM, int BN, bool AMASK = false>
+template <int BM, int BN, bool AMASK = false, int MMA = 0>
 __device__ __forceinline__ void smallp_tile(
     const float* __restrict__ dY, const float* __restrict__ X, float* __restrict__ dw, float* __restrict__ dbias,
     int P, int Co, int Ci, int want_bias, int accumulate, float* lds, unsigned block, unsigned nblocks,
@@ -563,7 +563,7 @@ __device__ __forceinline__ void smallp_tile(
         float a[FM][8], b[FN][8];
         read_kstrided<FM, AP>(As + wm, lane, ks, a);
         read_kstrided<FN, BP>(Bs + wn, lane, ks, b);
-        mma_step<FM, FN>(a, b, acc);
+        mma_any<MMA, FM, FN>(a, b, acc);
     }
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
@@ -593,13 +593,13 @@ __device__ __forceinline__ void smallp_tile(
     }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int MMA = 0>
 __global__ __launch_bounds__(THREADS) void linear_wgrad_smallp_kernel(
     const float* __restrict__ dY, const float* __restrict__ X, float* __restrict__ dw, float* __restrict__ dbias,
     int P, int Co, int Ci, int want_bias, int accumulate)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    smallp_tile<BM, BN>(dY, X, dw, dbias, P, Co, Ci, want_bias, accumulate, lds, blockIdx.x, gridDim.x);
+    smallp_tile<BM, BN, false, MMA>(dY, X, dw, dbias, P, Co, Ci, want_bias, accumulate, lds, blockIdx.x, gridDim.x);
 }
 
 // Backward of a Linear layer over few rows in ONE launch: the first `dgrad_tiles` workgroups compute the data gradient
@@ -608,7 +608,7 @@ __global__ __launch_bounds__(THREADS) void linear_wgrad_smallp_kernel(
 // launch removes one ~8 us dependent launch per layer (there are ~270 such layers in a step).
 // AMASK: dY is the gradient of relu(x w^T + b); ymask is that layer's saved output and both roles apply the ReLU mask while
 // they stage dY (no separate relu-backward launch, no masked copy of dY in memory).
-template <bool UNI, bool AMASK>
+template <bool UNI, bool AMASK, int MMA = 0>
 __global__ __launch_bounds__(THREADS) void linear_bwd_fused_kernel(
     const float* __restrict__ dY, const float* __restrict__ W, const float* __restrict__ X, const float* __restrict__ ymask,
     float* __restrict__ dX, float* __restrict__ dw, float* __restrict__ dbias,
@@ -616,9 +616,9 @@ __global__ __launch_bounds__(THREADS) void linear_bwd_fused_kernel(
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     if (blockIdx.x < dgrad_tiles)
-        igemm_tile<64, 64, true, 64, UNI, AMASK>(dY, W, nullptr, nullptr, dX, gd, 0, lds, blockIdx.x, dgrad_tiles, 0, ymask);
+        igemm_tile<64, 64, true, 64, UNI, AMASK, MMA>(dY, W, nullptr, nullptr, dX, gd, 0, lds, blockIdx.x, dgrad_tiles, 0, ymask);
     else
-        smallp_tile<64, 64, AMASK>(dY, X, dw, dbias, P, Co, Ci, want_bias, accumulate, lds, blockIdx.x - dgrad_tiles,
+        smallp_tile<64, 64, AMASK, MMA>(dY, X, dw, dbias, P, Co, Ci, want_bias, accumulate, lds, blockIdx.x - dgrad_tiles,
                                    gridDim.x - dgrad_tiles, ymask);
 }
 
@@ -659,19 +659,33 @@ __global__ void pad_channels_kernel(const float* __restrict__ src, float* __rest
 
 struct TileChoice { int bm, bn; };
 
+int g_mma_mode = 0;                                          // 0: f32-input MFMA (product default); 1: split-bf16 MFMA (phnet_tune_mma)
+
 TileChoice pick_tile(long M, long N)
 {
     // Measured on MI355X (tests/tools/bench_conv.py): the problems of this path are small (a 5-frame clip), so what
     // matters is the number of co-resident workgroups per CU, not the tile's arithmetic intensity: 64x64 tiles with
     // the block count topped up to ~1250 by split-K beat the larger tiles on every trunk layer (72-80 us vs 85-130 us).
-    (void)M; (void)N;
+    if (g_mma_mode == 1) {
+        // split-bf16: the loop is bound by the operand split (VALU) and the LDS reads per MFMA, both of which shrink with
+        // the wave tile - problems with enough tiles take the larger ones (bench_conv.py --mma --clips 8: 128x128 is
+        // 15-20 % faster than 64x64 on the 8-clip trunk layers, and slower on every 1-clip layer)
+        if (N >= 128 && ceil_div64(M, 128) * ceil_div64(N, 128) >= 300) return {128, 128};
+        if (ceil_div64(M, 128) * ceil_div64(N, 64) >= 1250) return {128, 64};
+    }
     return {64, 64};
 }
 
 struct ConvPlan { int bm, bn, splits; long tiles; };
 
-// K-tile depth: 64 for the skinny (latency-bound) GEMMs of the lane head, 16 otherwise
-int k_tile_for(long M, int K) { return (M <= 2048 && K >= 64) ? 64 : BK; }
+// K-tile depth: 64 for the skinny (latency-bound) GEMMs of the lane head, 16 otherwise; split-bf16 on 64x64 tiles: 32
+// (the MFMA work per barrier is 5x shorter there; measured 44-54 us vs 51-58 us on the trunk layers)
+int k_tile_for(long M, int K, int ci, int bm, int bn)
+{
+    if (M <= 2048 && K >= 64) return 64;
+    if (g_mma_mode == 1 && bm == 64 && bn == 64 && ci % 32 == 0) return 32;
+    return BK;
+}
 
 int g_force_bm = 0, g_force_bn = 0, g_force_splits = 0;      // tuning aid (phnet_tune_force_conv_tile)
 int g_force_kt = 0;                                          // tuning aid (phnet_tune_force_k_tile)
@@ -715,21 +729,26 @@ int launch_conv(const float* X, const float* W, const float* bias, const float* 
     float* dst = splits > 1 ? workspace : out;
     dim3 grid((unsigned)tiles, 1, (unsigned)splits);
     // deep K tiles for skinny (latency-bound) problems: few row tiles and K long enough to fill them
-    const int bkt = g_force_kt ? g_force_kt : k_tile_for(M, K);
+    const int bkt = g_force_kt ? g_force_kt : k_tile_for(M, K, g.Ci, t.bm, t.bn);
     const int ksteps = (K + bkt - 1) / bkt;
     g.k_per_split = ((ksteps + splits - 1) / splits) * bkt;
-#define PHNET_LAUNCH_CONV_(BM_, BN_, BKT_, UNI_)                                                                        \
+#define PHNET_LAUNCH_CONV__(BM_, BN_, BKT_, UNI_, MMA_)                                                                 \
     do {                                                                                                                \
         constexpr size_t lds_ = 2 * (KContigTile<BM_, BKT_>::FLOATS +                                                   \
                                      (DGRAD ? KStridedTile<BN_, BKT_>::FLOATS : KContigTile<BN_, BKT_>::FLOATS)) * 4;   \
         static bool attr_set_ = false;                                                                                  \
         if (lds_ > 64 * 1024 && !attr_set_) {                                                                           \
-            (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BM_, BN_, DGRAD, BKT_, UNI_>,                      \
+            (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BM_, BN_, DGRAD, BKT_, UNI_, MMA_>,                \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_);                                 \
             attr_set_ = true;                                                                                           \
         }                                                                                                               \
-        hipLaunchKernelGGL((conv_igemm_kernel<BM_, BN_, DGRAD, BKT_, UNI_>), grid, dim3(THREADS), lds_, st, X, W, bias, \
-                           addend, dst, g, relu);                                                                       \
+        hipLaunchKernelGGL((conv_igemm_kernel<BM_, BN_, DGRAD, BKT_, UNI_, MMA_>), grid, dim3(THREADS), lds_, st, X, W, \
+                           bias, addend, dst, g, relu);                                                                 \
+    } while (0)
+#define PHNET_LAUNCH_CONV_(BM_, BN_, BKT_, UNI_)                                                                        \
+    do {                                                                                                                \
+        if (g_mma_mode == 1) PHNET_LAUNCH_CONV__(BM_, BN_, BKT_, UNI_, 1);                                              \
+        else PHNET_LAUNCH_CONV__(BM_, BN_, BKT_, UNI_, 0);                                                              \
     } while (0)
 #define PHNET_LAUNCH_CONV(BM_, BN_, UNI_)                                                                               \
     do {                                                                                                                \
@@ -744,6 +763,7 @@ int launch_conv(const float* X, const float* W, const float* bias, const float* 
     else if (t.bm == 64 && t.bn == 128) PHNET_LAUNCH_CONV(64, 128, false);
     else if (uni) PHNET_LAUNCH_CONV(64, 64, true);
     else PHNET_LAUNCH_CONV(64, 64, false);
+#undef PHNET_LAUNCH_CONV__
 #undef PHNET_LAUNCH_CONV_
 #undef PHNET_LAUNCH_CONV
     if (splits > 1) {
@@ -764,7 +784,7 @@ PHNET_API int phnet_conv2d_plan(int64_t M, int32_t Co, int32_t K, uint64_t ws_by
     if (M < 1 || Co < 1 || K < 1 || !bm || !bn || !splits || !k_tile) return PHNET_ERR_ARG;
     const ConvPlan p = plan_conv((long)M, Co, K, ws_bytes > 0, (size_t)ws_bytes);
     *bm = p.bm; *bn = p.bn; *splits = p.splits;
-    *k_tile = g_force_kt ? g_force_kt : k_tile_for((long)M, K);
+    *k_tile = g_force_kt ? g_force_kt : k_tile_for((long)M, K, K, p.bm, p.bn);   // (K stands in for the channel count)
     return PHNET_OK;
 }
 
@@ -781,6 +801,14 @@ PHNET_API int phnet_tune_wgrad(int32_t allow_bm128, int32_t target_blocks)
 {
     if (target_blocks < 1) return PHNET_ERR_ARG;
     g_wgrad_bm128 = allow_bm128 & 1; g_wgrad_smallp = !(allow_bm128 & 2); g_wgrad_target = target_blocks;
+    return PHNET_OK;
+}
+
+// Tuning aid (process-global): arithmetic of the GEMM kernels.  0 = f32-input MFMA (default), 1 = split-bf16 (igemm.h).
+PHNET_API int phnet_tune_mma(int32_t mode)
+{
+    if (mode != 0 && mode != 1) return PHNET_ERR_ARG;
+    g_mma_mode = mode;
     return PHNET_OK;
 }
 
@@ -884,14 +912,19 @@ PHNET_API int phnet_conv2d_wgrad(const float* dy, const float* x, float* dw, flo
         const int P16 = ((int)P + 15) & ~15;
         const size_t lds = (size_t)P16 * (64 + 4) * 2 * sizeof(float);
         static bool attr = false;
-        if (lds > 64 * 1024 && !attr) {
-            if (hipFuncSetAttribute((const void*)linear_wgrad_smallp_kernel<64, 64>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)((size_t)SMALLP_MAX * 68 * 2 * sizeof(float))) != hipSuccess)
+        if (!attr) {
+            const int cap = (int)((size_t)SMALLP_MAX * 68 * 2 * sizeof(float));
+            if (hipFuncSetAttribute((const void*)linear_wgrad_smallp_kernel<64, 64, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
+                hipFuncSetAttribute((const void*)linear_wgrad_smallp_kernel<64, 64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess)
                 return PHNET_ERR_LAUNCH;
             attr = true;
         }
         const long tiles = ceil_div64(Co, 64) * ceil_div64(Ci, 64);
-        hipLaunchKernelGGL((linear_wgrad_smallp_kernel<64, 64>), dim3((unsigned)tiles), dim3(THREADS), lds, st, dy, x, dw, dbias,
+        if (g_mma_mode == 1)
+            hipLaunchKernelGGL((linear_wgrad_smallp_kernel<64, 64, 1>), dim3((unsigned)tiles), dim3(THREADS), lds, st, dy, x, dw, dbias,
+                               (int)P, Co, Ci, dbias != nullptr, accumulate);
+        else
+        hipLaunchKernelGGL((linear_wgrad_smallp_kernel<64, 64, 0>), dim3((unsigned)tiles), dim3(THREADS), lds, st, dy, x, dw, dbias,
                            (int)P, Co, Ci, dbias != nullptr, accumulate);
         return phnet_launch_status();
     }
@@ -907,7 +940,11 @@ PHNET_API int phnet_conv2d_wgrad(const float* dy, const float* x, float* dw, flo
     float* out = splits > 1 ? (float*)workspace : dw;
     dim3 grid((unsigned)tiles, 1, (unsigned)splits);
     const int want_bias = dbias != nullptr;
-    if (bm == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, 64>), grid, dim3(THREADS), 0, st, dy, x, out, dbias, g, want_bias, accumulate);
+    if (bm == 128 && g_mma_mode == 1)
+        hipLaunchKernelGGL((conv_wgrad_kernel<128, 64, 1>), grid, dim3(THREADS), 0, st, dy, x, out, dbias, g, want_bias, accumulate);
+    else if (g_mma_mode == 1)
+        hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 1>), grid, dim3(THREADS), 0, st, dy, x, out, dbias, g, want_bias, accumulate);
+    else if (bm == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, 64>), grid, dim3(THREADS), 0, st, dy, x, out, dbias, g, want_bias, accumulate);
     else hipLaunchKernelGGL((conv_wgrad_kernel<64, 64>), grid, dim3(THREADS), 0, st, dy, x, out, dbias, g, want_bias, accumulate);
     if (splits > 1) {
         const long nw = (long)Co * NC, nb = Co;
@@ -973,21 +1010,29 @@ PHNET_API int phnet_linear_bwd(const float* dy, const float* x, const float* w, 
     static bool attr = false;
     if (!attr) {
         const int cap = (int)((size_t)SMALLP_MAX * 68 * 2 * sizeof(float));
-        const void* fns[4] = {(const void*)linear_bwd_fused_kernel<true, true>, (const void*)linear_bwd_fused_kernel<true, false>,
-                              (const void*)linear_bwd_fused_kernel<false, true>, (const void*)linear_bwd_fused_kernel<false, false>};
+        const void* fns[8] = {(const void*)linear_bwd_fused_kernel<true, true, 0>, (const void*)linear_bwd_fused_kernel<true, false, 0>,
+                              (const void*)linear_bwd_fused_kernel<false, true, 0>, (const void*)linear_bwd_fused_kernel<false, false, 0>,
+                              (const void*)linear_bwd_fused_kernel<true, true, 1>, (const void*)linear_bwd_fused_kernel<true, false, 1>,
+                              (const void*)linear_bwd_fused_kernel<false, true, 1>, (const void*)linear_bwd_fused_kernel<false, false, 1>};
         for (const void* f : fns)
             if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess) return PHNET_ERR_LAUNCH;
         attr = true;
     }
     hipStream_t st = (hipStream_t)stream;
     const bool uni = N % 64 == 0 && g_uniform_tap;
+#define PHNET_LAUNCH_BWD_(U_, A_, MMA_)                                                                                 \
+    hipLaunchKernelGGL((linear_bwd_fused_kernel<U_, A_, MMA_>), dim3(dt + wt), dim3(THREADS), lds, st, dy, w, x, relu_y, dx, \
+                       dw, dbias, g, dt, (int)M, (int)N, (int)K, dbias != nullptr, accumulate)
 #define PHNET_LAUNCH_BWD(U_, A_)                                                                                        \
-    hipLaunchKernelGGL((linear_bwd_fused_kernel<U_, A_>), dim3(dt + wt), dim3(THREADS), lds, st, dy, w, x, relu_y, dx, dw, \
-                       dbias, g, dt, (int)M, (int)N, (int)K, dbias != nullptr, accumulate)
+    do {                                                                                                                \
+        if (g_mma_mode == 1) PHNET_LAUNCH_BWD_(U_, A_, 1);                                                              \
+        else PHNET_LAUNCH_BWD_(U_, A_, 0);                                                                              \
+    } while (0)
     if (uni && relu_y) PHNET_LAUNCH_BWD(true, true);
     else if (uni) PHNET_LAUNCH_BWD(true, false);
     else if (relu_y) PHNET_LAUNCH_BWD(false, true);
     else PHNET_LAUNCH_BWD(false, false);
 #undef PHNET_LAUNCH_BWD
+#undef PHNET_LAUNCH_BWD_
     return phnet_launch_status();
 }

@@ -67,6 +67,46 @@ __device__ __forceinline__ void mma_step(const float (&a)[FM][8], const float (&
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
 }
 
+// ---- split-bf16 arithmetic (MMA = 1, opt-in through phnet_tune_mma; the product default stays f32-input MFMA) --------
+// Every f32 operand is split in registers into two bf16 terms x = hi + lo (hi = bf16(x), lo = bf16(x - hi): 16 mantissa
+// bits) and a product becomes hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with f32 accumulation (the dropped
+// lo*lo term and the split residual are ~2^-16 relative per product).  The fragment registers are the SAME as for the
+// f32 MFMA - lane (r, h) holds k = 8h .. 8h+7 of its row / column for both instructions - so the LDS images, the staging
+// and the epilogues do not change: 3 MFMAs of 32 cycles replace 8 of 64 per 16-deep sub-step.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split_bf16(const float (&x)[8], bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const __bf16 h = (__bf16)x[s];
+        hi[s] = h;
+        lo[s] = (__bf16)(x[s] - (float)h);
+    }
+}
+
+template <int FM, int FN>
+__device__ __forceinline__ void mma_step_split(const float (&a)[FM][8], const float (&b)[FN][8], f32x16 (&acc)[FM][FN]) {
+    bf16x8 ah[FM], al[FM], bh[FN], bl[FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) split_bf16(a[i], ah[i], al[i]);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) split_bf16(b[j], bh[j], bl[j]);
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+}
+
+template <int MMA, int FM, int FN>
+__device__ __forceinline__ void mma_any(const float (&a)[FM][8], const float (&b)[FN][8], f32x16 (&acc)[FM][FN]) {
+    if (MMA == 1) mma_step_split<FM, FN>(a, b, acc);
+    else mma_step<FM, FN>(a, b, acc);
+}
+
 // C/D fragment element `reg` of lane `lane` sits at (row, col) of the 32x32 tile:
 __device__ __forceinline__ int frag_row(int lane, int reg) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 __device__ __forceinline__ int frag_col(int lane) { return lane & 31; }

@@ -704,3 +704,11 @@ def lane_decode(lines, conf_thresh: float, nms_thresh: float, top_k: int, img_w:
                                   _ptr(out["keep_mask"]), _ptr(out["num"]), _ptr(out["keep_c"]), _ptr(out["anchors"]),
                                   _ptr(out["anchors_sorted"]), _ptr(out["kept_rows"]), _stream()), "phnet_lane_decode")
     return out if batched else {k: v[0] for k, v in out.items()}
+
+
+def set_mma_mode(mode: str) -> None:
+    """Arithmetic of the conv / linear GEMM kernels (process-global; set it before a step is captured in a hipGraph):
+    "f32" = f32-input MFMA (default), "split_bf16" = operands split into two bf16 terms in registers, 3 bf16 MFMAs per
+    product, f32 accumulation (csrc/igemm.h)."""
+    code = {"f32": 0, "split_bf16": 1}[mode]
+    check(lib().phnet_tune_mma(code), "phnet_tune_mma")

@@ -146,6 +146,64 @@ def test_conv_fwd_dgrad_wgrad(ops, case):
     close(db, 2 * gy.sum(dim=(0, 2, 3)), 2e-5)
 
 
+@pytest.fixture
+def split_bf16(ops):
+    """GEMM kernels in split-bf16 arithmetic for the duration of one test (process-global switch, restored afterwards)."""
+    ops.set_mma_mode("split_bf16")
+    yield
+    ops.set_mma_mode("f32")
+
+
+# every code path of CONV_CASES (tiles, split-K, ragged, stem, linears) once more in the opt-in split-bf16 arithmetic:
+# two bf16 terms per operand, three bf16 MFMAs per product, f32 accumulation - ~2^-16 per product, 4-5e-6 of the output
+# scale measured on the hot shapes (tests/tools/bench_mma.py); held to 5e-5 here (f32-input MFMA: 2e-5)
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad_split_bf16(ops, split_bf16, case):
+    N, Hi, Wi, Ci, Co, R, stride, pad = case
+    torch.manual_seed(sum(case) + 1)
+    x = torch.randn(N, Ci, Hi, Wi, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn(Co, Ci, R, R, dtype=torch.float64) / (Ci * R * R) ** 0.5).requires_grad_(True)
+    b = torch.randn(Co, dtype=torch.float64)
+    ref = F.conv2d(x, w, b, stride=stride, padding=pad)
+    gy = torch.randn_like(ref)
+    ref.backward(gy)
+    xd, wd, gyd = nhwc(x.detach().float()), nhwc(w.detach().float()), nhwc(gy.float())
+    close(ops.conv2d_fwd(xd, wd, dev(b.float()), stride, pad, relu=True), F.relu(ref).permute(0, 2, 3, 1), 5e-5)
+    close(ops.conv2d_dgrad(gyd, wd, (Hi, Wi), stride, pad), x.grad.permute(0, 2, 3, 1), 5e-5)
+    db = torch.full((Co,), 7.0, device="cuda")
+    dw = ops.conv2d_wgrad(gyd, xd, wd.shape, stride, pad, dbias=db)
+    close(dw, w.grad.permute(0, 2, 3, 1), 5e-5)
+    close(db, gy.sum(dim=(0, 2, 3)), 2e-5)                           # the bias gradient stays an f32 sum
+    ops.conv2d_wgrad(gyd, xd, wd.shape, stride, pad, dw=dw, accumulate=True)
+    close(dw, 2 * w.grad.permute(0, 2, 3, 1), 5e-5)
+
+
+def test_split_bf16_large_problem_takes_the_large_tiles(ops, split_bf16):
+    """Problems with thousands of tiles run on 128x128 / 128x64 tiles in split-bf16 mode (conv.hip pick_tile)."""
+    torch.manual_seed(5)
+    for (N, Hi, Wi, Ci, Co) in [(4, 40, 100, 128, 128), (8, 80, 200, 64, 64)]:
+        x = torch.randn(N, Hi, Wi, Ci, device="cuda"); w = torch.randn(Co, 3, 3, Ci, device="cuda") / (9 * Ci) ** 0.5
+        ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), None, 1, 1).permute(0, 2, 3, 1)
+        close(ops.conv2d_fwd(x, w, None, 1, 1), ref, 5e-5)
+        gy = torch.randn_like(x[..., :Co])
+        refd = torch.nn.grad.conv2d_input((N, Ci, Hi, Wi), w.permute(0, 3, 1, 2).double(), gy.permute(0, 3, 1, 2).double(), 1, 1)
+        close(ops.conv2d_dgrad(gy, w, (Hi, Wi), 1, 1), refd.permute(0, 2, 3, 1), 5e-5)
+
+
+@pytest.mark.parametrize("M,K,N", [(240, 128, 384), (240, 192, 44), (37, 64, 64), (240, 2304, 576)])
+def test_linear_backward_fused_launch_split_bf16(ops, split_bf16, M, K, N):
+    torch.manual_seed(M + K + N + 1)
+    x = torch.randn(M, K, dtype=torch.float64)
+    w = torch.randn(N, K, dtype=torch.float64) / K ** 0.5
+    dy = torch.randn(M, N, dtype=torch.float64)
+    y = torch.relu(torch.randn(M, N, dtype=torch.float64))
+    gm = dy * (y > 0)
+    dw0, db0 = torch.randn(N, K, dtype=torch.float64), torch.randn(N, dtype=torch.float64)
+    dwd, dbd = dev(dw0.float()), dev(db0.float())
+    dx = ops.linear_bwd(dev(dy.float()), dev(x.float()), dev(w.float()), dwd, dbd, accumulate=True, relu_y=dev(y.float()))
+    close(dx, gm @ w, 5e-5); close(dwd, dw0 + gm.t() @ x, 5e-5); close(dbd, db0 + gm.sum(0), 3e-5)
+
+
 def test_linear_wrappers(ops):
     torch.manual_seed(1)
     x = torch.randn(240, 2304, dtype=torch.float64, requires_grad=True)

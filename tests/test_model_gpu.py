@@ -23,6 +23,7 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 ACT_TOL = 1e-3
 CASCADE_TOL = 5e-2
+CASCADE_FRAC = 0.99      # share of chained-stage elements that must be within ACT_TOL (module docstring)
 
 
 def _gold(name):
@@ -74,7 +75,7 @@ def _close_lines(a, b, what="", cascade=False):
         sane = (b[..., 6:].abs().amax(dim=-1) <= 2.0)
         frac = float((err <= ACT_TOL).double().mean())
         worst = float(err[sane].max()) if bool(sane.any()) else 0.0
-        assert frac >= 0.99 and worst <= CASCADE_TOL and bool(torch.isfinite(a).all()), (what, frac, worst)
+        assert frac >= CASCADE_FRAC and worst <= CASCADE_TOL and bool(torch.isfinite(a).all()), (what, frac, worst)
 
 
 def _record_heads(model):
@@ -118,7 +119,7 @@ def _train_case(g, T, gold_file, grad_names_file, grad_rtol=2e-2, grad_rms_atol=
         if t == 0:
             _close(ga[0], gb[0], what="gate t=0 stage 0")
         gerr = (ga - gb).abs()
-        assert float((gerr <= ACT_TOL).double().mean()) >= 0.99 and float(gerr.max()) <= CASCADE_TOL, (f"gate t={t}", float(gerr.max()))
+        assert float((gerr <= ACT_TOL).double().mean()) >= CASCADE_FRAC and float(gerr.max()) <= CASCADE_TOL, (f"gate t={t}", float(gerr.max()))
         if "train_fir" in gold:
             _close_lines(rec["fir"][t][0], gold["train_fir"][t][0], what=f"fir t={t} stage 0", cascade=t > 0)
             _close_lines(rec["sec"][t][0], gold["train_sec"][t][0], what=f"sec t={t} stage 0", cascade=t > 0)
@@ -218,6 +219,43 @@ def test_config2_clip_r34_train_parity():
 
 def test_config2_clip_r34_eval_parity():
     _eval_case(O.Geometry(arch="resnet34"), 5, "config2_r34_320x800.npz")
+
+
+def test_split_bf16_arithmetic_tracks_the_default_arithmetic():
+    """Opt-in split-bf16 GEMM arithmetic (hip_ops.set_mma_mode; 3 bf16 MFMAs per product, f32 accumulation): its rounding
+    noise is 4-5e-6 of a GEMM's output scale, ~4x the f32-input MFMA's, and the refinement cascade of this random-init
+    network amplifies any noise ~1000x (module docstring) - measured end to end: clip loss 3e-3 relative off the
+    reference goldens, chained-stage lines 97 % inside 1e-3 with outliers to 7e-2.  That is OUTSIDE the parity bounds the
+    default arithmetic meets above, which is why the mode is opt-in and never what bench.py's headline runs; this test
+    pins what it does deliver: stage-0 activations (no cascade) inside ACT_TOL, loss within 1e-2, gradient norms of 95 %
+    of the parameters within 5 % of the default arithmetic's."""
+    from phnet_amd import hip_ops
+    g = O.Geometry(img_h=64, img_w=160, arch="resnet18")
+    gold = _gold("tiny_r18_64x160.npz")
+    T = 3
+    frames, lanes = synth.make_clip(g, T).cuda(), synth.make_targets(g, T).cuda()
+    out = {}
+    try:
+        for mode in ("f32", "split_bf16"):
+            hip_ops.set_mma_mode(mode)
+            model = _build(g)
+            model.train()
+            rec, undo = _record_heads(model)
+            loss = model({"frame": frames, "lanes": lanes})
+            loss.backward()
+            torch.cuda.synchronize()
+            undo()
+            out[mode] = (float(loss.detach()), {k: float(p.grad.double().norm()) for k, p in model.named_parameters() if p.grad is not None}, rec)
+    finally:
+        hip_ops.set_mma_mode("f32")
+    (l0, g0, _), (l1, g1, rec) = out["f32"], out["split_bf16"]
+    _close(rec["gate"][0][0], gold["train_gate"][0][0], what="gate t=0 stage 0")
+    _close_lines(rec["fir"][0][0], gold["train_fir"][0][0], what="fir t=0 stage 0")
+    _close_lines(rec["sec"][0][0], gold["train_sec"][0][0], what="sec t=0 stage 0")
+    assert abs(l1 - l0) <= 1e-2 * abs(l0), (l0, l1)
+    assert abs(l1 - gold["train_loss"]) <= 1e-2 * abs(gold["train_loss"])
+    rel = np.array([abs(g1[k] - g0[k]) / (g0[k] + 1e-6) for k in g0])
+    assert float((rel <= 5e-2).mean()) >= 0.95, (float(np.sort(rel)[-10:].min()), float(rel.max()))
 
 
 @pytest.mark.parametrize("training", [True, False])

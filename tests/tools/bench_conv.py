@@ -6,6 +6,7 @@ from phnet_amd import hip_ops as K
 from phnet_amd._lib import lib
 
 TRUNK_ONLY = "--trunk" in sys.argv
+CLIPS = int(sys.argv[sys.argv.index("--clips") + 1]) if "--clips" in sys.argv else 1    # frames of CLIPS clips in one trunk pass
 SHAPES = [  # name, N,Hi,Wi,Ci,Co,R,stride,pad
     ("layer1 3x3", 5, 80, 200, 64, 64, 3, 1, 1),
     ("layer2 3x3", 5, 40, 100, 128, 128, 3, 1, 1),
@@ -40,7 +41,11 @@ def timeit(fn, iters=20):
     return e0.elapsed_time(e1) / (5 * iters) * 1e3  # us
 
 def main():
+    if "--mma" in sys.argv:
+        assert lib().phnet_tune_mma(1) == 0
+        print("split-bf16 arithmetic")
     for name, N, Hi, Wi, Ci, Co, R, st, pad in (SHAPES[:4] if TRUNK_ONLY else SHAPES):
+        N *= CLIPS
         x = torch.randn(N, Hi, Wi, Ci, device="cuda"); w = torch.randn(Co, R, R, Ci, device="cuda") * 0.05
         ho, wo = K.conv_out_hw(Hi, Wi, R, R, st, pad)
         gy = torch.randn(N, ho, wo, Co, device="cuda")
@@ -51,7 +56,7 @@ def main():
             ktiles = [16, 32, 64]
         cfgs = [(0, 0)] if "--quick" in sys.argv else [(0, 0), (64, 64), (128, 64), (64, 128), (128, 128)]
         if "--ktile" in sys.argv:
-            cfgs = [(64, 64), (128, 64)]
+            cfgs = [(64, 64), (128, 64), (128, 128)]
         for kt_, (bm, bn) in [(k_, c_) for k_ in ktiles for c_ in cfgs]:
             lib().phnet_tune_force_k_tile(kt_)
             for sp in ([0] if bm == 0 else ([1, 2, 4] if "--ktile" in sys.argv else [1, 2, 4, 8, 16])):
