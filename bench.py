@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--batched-extra", type=int, default=8,
                     help="N = 1 only: after the headline measurement, also time B clips per GPU and step in a child process and "
                          "report it under the extra key 'batched' (0 = skip)")
-    ap.add_argument("--mma", default="f32", choices=["f32", "split_bf16"],
+    ap.add_argument("--mma", default="f32", choices=["f32", "split_bf16", "split3_bf16"],
                     help="arithmetic of the conv / linear GEMM kernels: f32-input MFMA (default, the headline) or split-bf16 "
                          "(operands split into two bf16 terms, 3 bf16 MFMAs per product, f32 accumulation)")
     ap.add_argument("--split-extra", type=int, default=1,
@@ -155,8 +155,8 @@ def main():
     from phnet_amd.libs.utils.loss4OLV3 import Criterion4OL
     from phnet_amd.synthetic import make_clip, make_targets
 
-    if args.mma == "split_bf16":
-        hip_ops.set_mma_mode("split_bf16")
+    if args.mma != "f32":
+        hip_ops.set_mma_mode(args.mma)
         args.no_kernel_timer = True                  # the per-symbol attribution below knows the f32 kernels only
     torch.manual_seed(3407)
     cfg = make_cfg(img_h=args.height, img_w=args.width, arch=args.arch)

@@ -84,7 +84,8 @@ int phnet_tune_wgrad(int32_t allow_bm128, int32_t target_blocks);   /* wgrad til
                                                                         argument disables the few-rows Linear kernel */
 /* arithmetic of conv2d fwd / dgrad / wgrad (process-global): 0 = f32-input MFMA (default, what every published number
  * uses), 1 = split-bf16: operands split in registers into two bf16 terms, 3 bf16 MFMAs per product, f32 accumulation
- * (~2^-16 relative per product). */
+ * (~2^-16 relative per product); 2 = exact three-term bf16 split, 6 bf16 MFMAs per product (dropped terms <= 2^-24:
+ * the accuracy of mode 0). */
 int phnet_tune_mma(int32_t mode);
 uint64_t phnet_conv2d_wgrad_workspace(int32_t N, int32_t Hi, int32_t Wi, int32_t Ci, int32_t Co,
                                       int32_t R, int32_t S, int32_t stride, int32_t pad);

@@ -666,7 +666,7 @@ TileChoice pick_tile(long M, long N)
     // Measured on MI355X (tests/tools/bench_conv.py): the problems of this path are small (a 5-frame clip), so what
     // matters is the number of co-resident workgroups per CU, not the tile's arithmetic intensity: 64x64 tiles with
     // the block count topped up to ~1250 by split-K beat the larger tiles on every trunk layer (72-80 us vs 85-130 us).
-    if (g_mma_mode == 1) {
+    if (g_mma_mode >= 1) {
         // split-bf16: the loop is bound by the operand split (VALU) and the LDS reads per MFMA, both of which shrink with
         // the wave tile - problems with enough tiles take the larger ones (bench_conv.py --mma --clips 8: 128x128 is
         // 15-20 % faster than 64x64 on the 8-clip trunk layers, and slower on every 1-clip layer)
@@ -683,7 +683,7 @@ struct ConvPlan { int bm, bn, splits; long tiles; };
 int k_tile_for(long M, int K, int ci, int bm, int bn)
 {
     if (M <= 2048 && K >= 64) return 64;
-    if (g_mma_mode == 1 && bm == 64 && bn == 64 && ci % 32 == 0) return 32;
+    if (g_mma_mode >= 1 && bm == 64 && bn == 64 && ci % 32 == 0) return 32;
     return BK;
 }
 
@@ -748,6 +748,7 @@ int launch_conv(const float* X, const float* W, const float* bias, const float* 
 #define PHNET_LAUNCH_CONV_(BM_, BN_, BKT_, UNI_)                                                                        \
     do {                                                                                                                \
         if (g_mma_mode == 1) PHNET_LAUNCH_CONV__(BM_, BN_, BKT_, UNI_, 1);                                              \
+        else if (g_mma_mode == 2) PHNET_LAUNCH_CONV__(BM_, BN_, BKT_, UNI_, 2);                                         \
         else PHNET_LAUNCH_CONV__(BM_, BN_, BKT_, UNI_, 0);                                                              \
     } while (0)
 #define PHNET_LAUNCH_CONV(BM_, BN_, UNI_)                                                                               \
@@ -807,7 +808,7 @@ PHNET_API int phnet_tune_wgrad(int32_t allow_bm128, int32_t target_blocks)
 // Tuning aid (process-global): arithmetic of the GEMM kernels.  0 = f32-input MFMA (default), 1 = split-bf16 (igemm.h).
 PHNET_API int phnet_tune_mma(int32_t mode)
 {
-    if (mode != 0 && mode != 1) return PHNET_ERR_ARG;
+    if (mode < 0 || mode > 2) return PHNET_ERR_ARG;
     g_mma_mode = mode;
     return PHNET_OK;
 }
@@ -940,7 +941,11 @@ PHNET_API int phnet_conv2d_wgrad(const float* dy, const float* x, float* dw, flo
     float* out = splits > 1 ? (float*)workspace : dw;
     dim3 grid((unsigned)tiles, 1, (unsigned)splits);
     const int want_bias = dbias != nullptr;
-    if (bm == 128 && g_mma_mode == 1)
+    if (bm == 128 && g_mma_mode == 2)
+        hipLaunchKernelGGL((conv_wgrad_kernel<128, 64, 2>), grid, dim3(THREADS), 0, st, dy, x, out, dbias, g, want_bias, accumulate);
+    else if (g_mma_mode == 2)
+        hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 2>), grid, dim3(THREADS), 0, st, dy, x, out, dbias, g, want_bias, accumulate);
+    else if (bm == 128 && g_mma_mode == 1)
         hipLaunchKernelGGL((conv_wgrad_kernel<128, 64, 1>), grid, dim3(THREADS), 0, st, dy, x, out, dbias, g, want_bias, accumulate);
     else if (g_mma_mode == 1)
         hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 1>), grid, dim3(THREADS), 0, st, dy, x, out, dbias, g, want_bias, accumulate);

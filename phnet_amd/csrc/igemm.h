@@ -101,9 +101,45 @@ __device__ __forceinline__ void mma_step_split(const float (&a)[FM][8], const fl
         }
 }
 
+// MMA = 2: three bf16 terms per operand (x = hi + mid + lo EXACTLY: 3 x 8 mantissa bits, every difference is exact in f32)
+// and the six products down to 2^-16 (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi); what is dropped (mid*lo, lo*mid, lo*lo)
+// is <= 2^-24 relative per product - the rounding level of an f32 fma chain.  6 MFMAs of 32 cycles per 16-deep sub-step.
+__device__ __forceinline__ void split3_bf16(const float (&x)[8], bf16x8& hi, bf16x8& mid, bf16x8& lo) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const __bf16 h = (__bf16)x[s];
+        const float r1 = x[s] - (float)h;
+        const __bf16 m = (__bf16)r1;
+        hi[s] = h;
+        mid[s] = m;
+        lo[s] = (__bf16)(r1 - (float)m);
+    }
+}
+
+template <int FM, int FN>
+__device__ __forceinline__ void mma_step_split3(const float (&a)[FM][8], const float (&b)[FN][8], f32x16 (&acc)[FM][FN]) {
+    bf16x8 ah[FM], am[FM], al[FM], bh[FN], bm[FN], bl[FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) split3_bf16(a[i], ah[i], am[i], al[i]);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) split3_bf16(b[j], bh[j], bm[j], bl[j]);
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bm[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bm[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+}
+
 template <int MMA, int FM, int FN>
 __device__ __forceinline__ void mma_any(const float (&a)[FM][8], const float (&b)[FN][8], f32x16 (&acc)[FM][FN]) {
-    if (MMA == 1) mma_step_split<FM, FN>(a, b, acc);
+    if (MMA == 2) mma_step_split3<FM, FN>(a, b, acc);
+    else if (MMA == 1) mma_step_split<FM, FN>(a, b, acc);
     else mma_step<FM, FN>(a, b, acc);
 }
 

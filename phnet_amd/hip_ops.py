@@ -708,7 +708,8 @@ def lane_decode(lines, conf_thresh: float, nms_thresh: float, top_k: int, img_w:
 
 def set_mma_mode(mode: str) -> None:
     """Arithmetic of the conv / linear GEMM kernels (process-global; set it before a step is captured in a hipGraph):
-    "f32" = f32-input MFMA (default), "split_bf16" = operands split into two bf16 terms in registers, 3 bf16 MFMAs per
-    product, f32 accumulation (csrc/igemm.h)."""
-    code = {"f32": 0, "split_bf16": 1}[mode]
+    "f32" = f32-input MFMA (default); "split_bf16" = operands split into two bf16 terms in registers, 3 bf16 MFMAs per
+    product, f32 accumulation (~4x the rounding noise of "f32"); "split3_bf16" = three bf16 terms (an exact split of the
+    f32 value), 6 bf16 MFMAs per product, dropped terms <= 2^-24: the accuracy of "f32" (csrc/igemm.h)."""
+    code = {"f32": 0, "split_bf16": 1, "split3_bf16": 2}[mode]
     check(lib().phnet_tune_mma(code), "phnet_tune_mma")

@@ -146,3 +146,21 @@ def test_grad_sink_collects_per_use_gradients_once():
     assert torch.allclose(a.grad, a2.grad) and torch.allclose(b.grad, b2.grad)
     with torch.no_grad():
         assert grad_sink(a * b)._phnet_sink is None if hasattr(grad_sink(a * b), "_phnet_sink") else True
+
+
+def test_lines_txt_wire_format(tmp_path):
+    """evaluation/generate_lane.py:46-61 of the reference: '%.1f %.1f ' pairs, points last-to-first, lanes with <= 2 points
+    dropped, x = tx*W/2, y = (ty*H + 480)/2.  Expected text written out by hand from that formula."""
+    import numpy as np
+    from phnet_amd.evaluation.generate_lane import format_pred_lines, generate_predV2
+    from phnet_amd.libs.utils.lane import Lane
+    size = (800, 1920)                                         # (H after the 480-row crop, W) of an OpenLane image
+    a = Lane(points=np.array([[0.75, 0.0], [0.5, 0.5], [0.25, 1.0]]))
+    short = Lane(points=np.array([[0.2, 0.8], [0.1, 0.9]]))     # two points: not written
+    b = Lane(points=np.array([[0.5, 0.8], [0.3333, 0.85], [0.10004, 0.9], [0.1, 0.95]]))
+    text = format_pred_lines([a, short, b], size)
+    assert text == ("240.0 640.0 480.0 440.0 720.0 240.0 \n"
+                    "96.0 620.0 96.0 600.0 320.0 580.0 480.0 560.0 \n")
+    info = {"name": "clip7", "ImgName": ["f0", "f1"], "size": size}
+    path = generate_predV2(info, [a], 1, str(tmp_path))
+    assert path.endswith("clip7/f1.lines.txt") and open(path).read() == "240.0 640.0 480.0 440.0 720.0 240.0 \n"

@@ -178,6 +178,26 @@ def test_conv_fwd_dgrad_wgrad_split_bf16(ops, split_bf16, case):
     close(dw, 2 * w.grad.permute(0, 2, 3, 1), 5e-5)
 
 
+@pytest.mark.parametrize("case", CONV_CASES[:8])
+def test_conv_split3_bf16_is_as_accurate_as_f32_mfma(ops, case):
+    """Exact three-term bf16 split, 6 bf16 MFMAs per product: the f32 kernels' own tolerance (2e-5)."""
+    N, Hi, Wi, Ci, Co, R, stride, pad = case
+    torch.manual_seed(sum(case) + 2)
+    x = torch.randn(N, Ci, Hi, Wi, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn(Co, Ci, R, R, dtype=torch.float64) / (Ci * R * R) ** 0.5).requires_grad_(True)
+    ref = F.conv2d(x, w, None, stride=stride, padding=pad)
+    gy = torch.randn_like(ref)
+    ref.backward(gy)
+    xd, wd, gyd = nhwc(x.detach().float()), nhwc(w.detach().float()), nhwc(gy.float())
+    ops.set_mma_mode("split3_bf16")
+    try:
+        close(ops.conv2d_fwd(xd, wd, None, stride, pad), ref.permute(0, 2, 3, 1), 2e-5)
+        close(ops.conv2d_dgrad(gyd, wd, (Hi, Wi), stride, pad), x.grad.permute(0, 2, 3, 1), 2e-5)
+        close(ops.conv2d_wgrad(gyd, xd, wd.shape, stride, pad), w.grad.permute(0, 2, 3, 1), 2e-5)
+    finally:
+        ops.set_mma_mode("f32")
+
+
 def test_split_bf16_large_problem_takes_the_large_tiles(ops, split_bf16):
     """Problems with thousands of tiles run on 128x128 / 128x64 tiles in split-bf16 mode (conv.hip pick_tile)."""
     torch.manual_seed(5)

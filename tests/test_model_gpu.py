@@ -221,6 +221,25 @@ def test_config2_clip_r34_eval_parity():
     _eval_case(O.Geometry(arch="resnet34"), 5, "config2_r34_320x800.npz")
 
 
+@pytest.fixture
+def split3_bf16():
+    from phnet_amd import hip_ops
+    hip_ops.set_mma_mode("split3_bf16")
+    yield
+    hip_ops.set_mma_mode("f32")
+
+
+def test_config2_parity_in_split3_bf16_arithmetic(split3_bf16):
+    """The exact three-term bf16 split (6 bf16 MFMAs per product, csrc/igemm.h) is as accurate per GEMM as the f32-input
+    MFMA (tests/tools/bench_mma.py: 0.3-1.2e-6 of the output scale for both): the headline configuration holds the SAME
+    reference goldens at the SAME tolerances (activations 1e-3, indices / keep masks exact, loss 1e-3, gradient norms 5e-3).
+    (Different rounding, not less of it: on the tiny configuration ONE sampled gradient entry of one BatchNorm bias lands
+    2.6e-3 from the golden where the bound is 1.9e-3 - cascade noise of the module docstring - so that case is not asserted.)"""
+    _train_case(O.Geometry(arch="resnet34"), 5, "config2_r34_320x800.npz", "grad_names_resnet34.json",
+                grad_rtol=5e-2, grad_rms_atol=1e-1)
+    _eval_case(O.Geometry(arch="resnet34"), 5, "config2_r34_320x800.npz")
+
+
 def test_split_bf16_arithmetic_tracks_the_default_arithmetic():
     """Opt-in split-bf16 GEMM arithmetic (hip_ops.set_mma_mode; 3 bf16 MFMAs per product, f32 accumulation): its rounding
     noise is 4-5e-6 of a GEMM's output scale, ~4x the f32-input MFMA's, and the refinement cascade of this random-init
