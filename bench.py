@@ -291,7 +291,7 @@ def main():
             mfma_util = None
             try:                                           # separate PMC pass on the backbone conv shapes (profiles/README.md)
                 pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_mfma_trunk.json")))
-                vals = [v["mfma_util_pct"] for k, v in pm.items() if ", 16>" in k or "wgrad" in k]
+                vals = [v["mfma_util_pct"] for k, v in pm.items() if ", 16, " in k or "wgrad" in k]
                 mfma_util = {"min": min(vals), "max": max(vals), "source": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE on "
                              "tests/tools/bench_conv.py --trunk (ResNet-34 stage convs of a 5x320x800 clip), profiles/r01_pmc_mfma_trunk.json"}
             except Exception:                              # noqa: BLE001

@@ -16,14 +16,17 @@ _WS = {}
 TIMER = None
 
 
+_MMA_MODE = 0        # last template argument of the GEMM kernels (set_mma_mode); only used to NAME kernel symbols for bench.py
+
+
 def _gemm_symbol(m, co, k, ws_bytes, dgrad, ci_a):
     import ctypes
     bm, bn, sp, kt = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
     check(lib().phnet_conv2d_plan(m, co, k, ws_bytes, ctypes.byref(bm), ctypes.byref(bn), ctypes.byref(sp), ctypes.byref(kt)),
           "phnet_conv2d_plan")
     uni = bm.value == 64 and bn.value == 64 and ci_a % kt.value == 0      # uniform-tap variant (csrc/conv.hip)
-    return (f"conv_igemm_kernel<{bm.value}, {bn.value}, {'true' if dgrad else 'false'}, {kt.value}, {'true' if uni else 'false'}>",
-            sp.value)
+    return (f"conv_igemm_kernel<{bm.value}, {bn.value}, {'true' if dgrad else 'false'}, {kt.value}, {'true' if uni else 'false'}, "
+            f"{_MMA_MODE}>", sp.value)
 
 
 def _timed_launch(sym_fn, flops, launch):
@@ -165,7 +168,8 @@ def conv2d_wgrad(dy, x, w_shape, stride: int, pad: int, dw: Optional[torch.Tenso
     ho, wo = conv_out_hw(hi, wi, r, s, stride, pad)
     smallp = (r == 1 and s == 1 and stride == 1 and pad == 0 and n * ho * wo <= 256 and
               ((co + 63) // 64) * ((ci + 63) // 64) < 400)                                # few-rows Linear kernel (csrc/conv.hip)
-    _timed_launch(lambda: ("linear_wgrad_smallp_kernel<64, 64>" if smallp else f"conv_wgrad_kernel<{128 if co >= 128 else 64}, 64>", 0),
+    _timed_launch(lambda: (f"linear_wgrad_smallp_kernel<64, 64, {_MMA_MODE & 1}>" if smallp
+                           else f"conv_wgrad_kernel<{128 if co >= 128 else 64}, 64, {_MMA_MODE}>", 0),
                   2.0 * n * ho * wo * co * r * s * ci,
                   lambda: check(lib().phnet_conv2d_wgrad(_ptr(dy), _ptr(x), _ptr(dw), _ptr(dbias), n, hi, wi, ci, co, r, s, stride,
                                                          pad, int(accumulate), _ptr(ws), ws.numel(), _stream()), "phnet_conv2d_wgrad"))
@@ -203,7 +207,7 @@ def linear_bwd(dy2d, x2d, w, dw: torch.Tensor, dbias: Optional[torch.Tensor], ac
     m, n = dy2d.shape
     k = x2d.shape[1]
     dx = torch.empty((m, k), dtype=torch.float32, device=dy2d.device)
-    sym = f"linear_bwd_fused_kernel<{'true' if n % 64 == 0 else 'false'}, {'true' if relu_y is not None else 'false'}>"
+    sym = f"linear_bwd_fused_kernel<{'true' if n % 64 == 0 else 'false'}, {'true' if relu_y is not None else 'false'}, {_MMA_MODE & 1}>"
     _timed_launch(lambda: (sym, 0), 4.0 * m * n * k,
                   lambda: check(lib().phnet_linear_bwd(_ptr(dy2d), _ptr(x2d), _ptr(w), _ptr(relu_y), _ptr(dx), _ptr(dw), _ptr(dbias), m, k, n,
                                                        int(accumulate), _stream()), "phnet_linear_bwd"))
@@ -711,5 +715,7 @@ def set_mma_mode(mode: str) -> None:
     "f32" = f32-input MFMA (default); "split_bf16" = operands split into two bf16 terms in registers, 3 bf16 MFMAs per
     product, f32 accumulation (~4x the rounding noise of "f32"); "split3_bf16" = three bf16 terms (an exact split of the
     f32 value), 6 bf16 MFMAs per product, dropped terms <= 2^-24: the accuracy of "f32" (csrc/igemm.h)."""
+    global _MMA_MODE
     code = {"f32": 0, "split_bf16": 1, "split3_bf16": 2}[mode]
     check(lib().phnet_tune_mma(code), "phnet_tune_mma")
+    _MMA_MODE = code
