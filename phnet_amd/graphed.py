@@ -36,10 +36,12 @@ class GraphedTrainStep:
             with torch.cuda.graph(self.graph):
                 self.loss = self._step(zero=arena is not None)
         else:
-            with torch.cuda.graph(self.graph):
+            # data-parallel: the RCCL watchdog thread of torch.distributed polls events while we capture; thread-local
+            # capture mode keeps its (unrelated) calls from invalidating the capture
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 self.loss = self._fwd_bwd(zero=arena is not None)
             self.graph_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_opt, pool=self.graph.pool()):
+            with torch.cuda.graph(self.graph_opt, pool=self.graph.pool(), capture_error_mode="thread_local"):
                 self.optimizer.step()
         torch.cuda.synchronize()
 
