@@ -9,6 +9,10 @@ from phnet_amd.libs.models.Router4OL import RouterOL
 from phnet_amd.synthetic import make_clip
 
 def main(clips=32, T=5, H=320, W=800, arch="resnet34"):
+    mma = sys.argv[sys.argv.index("--mma") + 1] if "--mma" in sys.argv else "f32"      # f32 | split_bf16 | split3_bf16 (opt-in arithmetics)
+    if mma != "f32":
+        from phnet_amd import hip_ops
+        hip_ops.set_mma_mode(mma)
     torch.manual_seed(0)
     model = RouterOL(make_cfg(img_h=H, img_w=W, arch=arch), None).cuda().eval()
     batch = [make_clip(H, W, T, seed=i).cuda() for i in range(4)]
@@ -43,7 +47,7 @@ def main(clips=32, T=5, H=320, W=800, arch="resnet34"):
             model({"frame": batch[i % 4], "lanes": None})
         torch.cuda.synchronize()
         eager = (time.perf_counter() - t1) / 4
-    print(json.dumps({"workload": f"{clips} clips x {T} frames 3x{H}x{W}, {arch}, eval, hipGraph", "clips_per_s": round(clips / dt, 2),
+    print(json.dumps({"workload": f"{clips} clips x {T} frames 3x{H}x{W}, {arch}, eval, hipGraph", "gemm_arithmetic": mma, "clips_per_s": round(clips / dt, 2),
                       "frames_per_s": round(clips * T / dt, 1), "ms_per_clip_graph": round(dt / clips * 1e3, 2),
                       "ms_per_clip_eager_sync_free": round(eager * 1e3, 2), "lanes_last_clip": [len(x) for x in host["lane_lines"]],
                       **batched, "frames_per_s_batched_32": round(batched["clips_per_s_batched_32"] * T, 1)}))
