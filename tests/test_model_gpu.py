@@ -147,7 +147,7 @@ def _train_case(g, T, gold_file, grad_names_file, grad_rtol=2e-2, grad_rms_atol=
     return model, worst
 
 
-def _eval_case(g, T, gold_file):
+def _eval_case(g, T, gold_file, pts_atol=ACT_TOL):
     gold = _gold(gold_file)
     model = _build(g)
     model.eval()
@@ -175,7 +175,7 @@ def _eval_case(g, T, gold_file):
         for j, lane in enumerate(lanes):
             n = int(gold["eval_lane_npts"][t, j])
             assert lane.points.shape == (n, 2)
-            np.testing.assert_allclose(lane.points, gold["eval_lane_pts"][t, j, :n], atol=ACT_TOL)
+            np.testing.assert_allclose(lane.points, gold["eval_lane_pts"][t, j, :n], atol=pts_atol)
 
 
 def test_tiny_train_parity_vs_reference_goldens():
@@ -238,6 +238,21 @@ def test_config2_parity_in_split3_bf16_arithmetic(split3_bf16):
     _train_case(O.Geometry(arch="resnet34"), 5, "config2_r34_320x800.npz", "grad_names_resnet34.json",
                 grad_rtol=5e-2, grad_rms_atol=1e-1)
     _eval_case(O.Geometry(arch="resnet34"), 5, "config2_r34_320x800.npz")
+
+
+def test_eval_parity_in_split_bf16_arithmetic():
+    """Inference in the two-term split-bf16 arithmetic against the reference goldens: keep masks and kept anchors stay
+    bit-exact and the chained-stage lines hold the default criterion (99 % inside 1e-3) on all three configurations; the
+    decoded lane points are within 2e-3 (one of 14 points of one config-2 lane lands 1.04e-3 from the golden - the
+    default arithmetic's bound is 1e-3, which is why this mode stays opt-in for inference too)."""
+    from phnet_amd import hip_ops
+    hip_ops.set_mma_mode("split_bf16")
+    try:
+        _eval_case(O.Geometry(arch="resnet34"), 5, "config2_r34_320x800.npz", pts_atol=2e-3)
+        _eval_case(O.Geometry(img_h=64, img_w=160, arch="resnet18"), 4, "tiny_r18_64x160.npz", pts_atol=2e-3)
+        _eval_case(O.Geometry(arch="resnet18"), 1, "config1_r18_320x800.npz", pts_atol=2e-3)
+    finally:
+        hip_ops.set_mma_mode("f32")
 
 
 def test_split_bf16_arithmetic_tracks_the_default_arithmetic():
