@@ -286,21 +286,32 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(
 }
 
 // out[i] = sum_z part[z][i] (+bias[i % ncols]) (relu)
+// Every operand of an output element is fetched before the first add (the first eight partial sums branch-free - a
+// split index past the end re-reads the last one - plus bias, addend and the old value): one memory latency per launch
+// instead of one per split.  The additions keep their order (z ascending, then bias, addend, relu, old value).
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ out,
                                                             const float* __restrict__ bias, const float* __restrict__ addend,
                                                             long total4, int ncols, int splits, int relu, int accumulate)
 {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total4) return;
-    f32x4 s = reinterpret_cast<const f32x4*>(part)[i];
-    for (int z = 1; z < splits; ++z) s += reinterpret_cast<const f32x4*>(part)[i + (long)z * total4];
-    if (bias) {
-        const int c = (int)((i * 4) % ncols);
-        s += *reinterpret_cast<const f32x4*>(bias + c);
-    }
-    if (addend) s += reinterpret_cast<const f32x4*>(addend)[i];
+    const f32x4* p = reinterpret_cast<const f32x4*>(part) + i;
+    const f32x4 zero{0.f, 0.f, 0.f, 0.f};
+    f32x4 v[8];
+#pragma unroll
+    for (int z = 0; z < 8; ++z) v[z] = p[(long)min(z, splits - 1) * total4];
+    const f32x4 bv = bias ? *reinterpret_cast<const f32x4*>(bias + (int)((i * 4) % ncols)) : zero;
+    const f32x4 av = addend ? reinterpret_cast<const f32x4*>(addend)[i] : zero;
+    const f32x4 ov = accumulate ? reinterpret_cast<const f32x4*>(out)[i] : zero;
+    f32x4 s = v[0];
+#pragma unroll
+    for (int z = 1; z < 8; ++z)
+        if (z < splits) s += v[z];
+    for (int z = 8; z < splits; ++z) s += p[(long)z * total4];
+    if (bias) s += bv;
+    if (addend) s += av;
     if (relu) { s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f); }
-    if (accumulate) s += reinterpret_cast<const f32x4*>(out)[i];
+    if (accumulate) s += ov;
     reinterpret_cast<f32x4*>(out)[i] = s;
 }
 
@@ -622,19 +633,43 @@ __global__ __launch_bounds__(THREADS) void linear_bwd_fused_kernel(
                                    gridDim.x - dgrad_tiles, ymask);
 }
 
-// dW (+)= sum_z part[z][0:nw],  dbias (+)= sum_z part[z][nw:nw+nb]   (part rows are nw+nb floats long)
+// dW (+)= sum_z part[z][0:nw],  dbias (+)= sum_z part[z][nw:nw+nb]   (part rows are nw+nb floats long; nw, nb multiples of 4)
+// 256 threads = 64 float4 columns x 4 split groups: group g sums the partials z = g, g+4, ... with four loads in flight, the
+// four group sums are folded through LDS in a fixed order (deterministic).  The small trunk layers run with 40-190 splits;
+// one thread per element walking all of them paid one L2 latency per split (22-62 us per launch, now a few).
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
                                                            float* __restrict__ dbias, long nw, long nb, int splits, int accumulate)
 {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nw + nb) return;
-    const long stride = nw + nb;
-    float* dst = i < nw ? dw + i : dbias + (i - nw);
-    if (i >= nw && !dbias) return;
-    const float old = accumulate ? *dst : 0.f;           // cold read first: it overlaps the partial sums
-    float s = part[i];
-    for (int z = 1; z < splits; ++z) s += part[i + (long)z * stride];
-    *dst = old + s;
+    __shared__ f32x4 red[3][64];
+    const int lane = threadIdx.x & 63, zg = threadIdx.x >> 6;
+    const long total4 = (nw + nb) >> 2;
+    const long i4 = (long)blockIdx.x * 64 + lane;
+    const bool ok = i4 < total4;
+    const long i = i4 * 4;
+    const bool is_w = i < nw;
+    const bool writer = zg == 0 && ok && (is_w || dbias);
+    const f32x4 zero{0.f, 0.f, 0.f, 0.f};
+    f32x4 old = zero;
+    if (writer && accumulate) {                           // cold read first: it overlaps the partial sums
+        if (is_w) old = *reinterpret_cast<const f32x4*>(dw + i);
+        else { const float* b = dbias + (i - nw); old = f32x4{b[0], b[1], b[2], b[3]}; }
+    }
+    const f32x4* p = reinterpret_cast<const f32x4*>(part) + (ok ? i4 : 0);
+    f32x4 s = zero;
+    int z = zg;
+    for (; z + 12 < splits; z += 16) {
+        const f32x4 v0 = p[(long)z * total4], v1 = p[(long)(z + 4) * total4], v2 = p[(long)(z + 8) * total4],
+                    v3 = p[(long)(z + 12) * total4];
+        s += v0; s += v1; s += v2; s += v3;
+    }
+    for (; z < splits; z += 4) s += p[(long)z * total4];
+    if (zg) red[zg - 1][lane] = s;
+    __syncthreads();
+    if (writer) {
+        const f32x4 t = old + ((s + red[0][lane]) + (red[1][lane] + red[2][lane]));
+        if (is_w) *reinterpret_cast<f32x4*>(dw + i) = t;
+        else { float* b = dbias + (i - nw); b[0] = t.x; b[1] = t.y; b[2] = t.z; b[3] = t.w; }
+    }
 }
 
 // ---- stem helpers: NCHW (3 ch) -> NHWC padded to 4 channels; OHWI weight pad 3->4 and back -----------
@@ -953,7 +988,7 @@ PHNET_API int phnet_conv2d_wgrad(const float* dy, const float* x, float* dw, flo
     else hipLaunchKernelGGL((conv_wgrad_kernel<64, 64>), grid, dim3(THREADS), 0, st, dy, x, out, dbias, g, want_bias, accumulate);
     if (splits > 1) {
         const long nw = (long)Co * NC, nb = Co;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div64(nw + nb, 256)), dim3(256), 0, st,
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div64((nw + nb) >> 2, 64)), dim3(256), 0, st,
                            (const float*)workspace, dw, dbias, nw, nb, (int)splits, accumulate);
     }
     return phnet_launch_status();
