@@ -904,7 +904,10 @@ PHNET_API int phnet_conv2d_dgrad(const float* dy, const float* w, const float* a
 // workspace must hold splits*Co*R*S*Ci floats; query with phnet_conv2d_wgrad_workspace.
 static long wgrad_splits(long P, long Co, long NC, int* bm_out)
 {
-    const int bm = (Co >= 128 && g_wgrad_bm128) ? 128 : 64;
+    // measured (bench_conv.py --trunk --wgrad, reduce included): on a 5-frame clip 128-row tiles win at Co = 128 only (73 vs 79 us);
+    // at Co = 256 / 512 (5000 / 1250 pixels) the 64x64 tile with more splits is 5 / 3 us faster; with 8 clips per step
+    // (40000 / 10000 pixels) the 128-row tile wins everywhere (step 129.7 vs 132.4 ms)
+    const int bm = (Co >= 128 && (Co < 256 || P > 8192) && g_wgrad_bm128) ? 128 : 64;
     const long tiles = ceil_div64(Co, bm) * ceil_div64(NC, 64);
     const long target = tiles >= 64 ? max((long)g_wgrad_target, (long)1250) : (long)g_wgrad_target;   // measured: bench_conv --wgrad
     long splits = max((long)1, min((long)256, target / max((long)1, tiles)));
