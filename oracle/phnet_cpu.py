@@ -521,6 +521,8 @@ def clip_forward(sd: State, frames: Tensor, lanes: Optional[Tensor], g: Geometry
         if collect is not None:
             collect.setdefault("frames", []).append(out)
             collect.setdefault("positives", []).append(positives)
+            if training:
+                collect.setdefault("frame_loss", []).append(float(loss_t.detach()))
         with torch.no_grad():
             memory.append(memory_tokens(out.attn_feats, positives))
             if t >= g.save_freq_max:

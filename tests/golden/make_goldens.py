@@ -139,8 +139,11 @@ def grad_digest(model):
     return names, np.array(norms), np.array([h[:4] for h in heads])
 
 
-def run_train(model, g, T, tag, out, keep_fpn=False, keep_preds=True):
-    frames, lanes = synth.make_clip(g, T), synth.make_targets(g, T)
+RAGGED_COUNTS = (0, 4, 1, 2)      # valid lanes per frame of the ragged case: none, the label's maximum, one, two
+
+
+def run_train(model, g, T, tag, out, keep_fpn=False, keep_preds=True, counts=None):
+    frames, lanes = synth.make_clip(g, T), synth.make_targets(g, T, counts=counts)
     model.train()
     model.zero_grad()
     rec = {"fir": [], "sec": [], "gate": [], "matched": []}
@@ -233,6 +236,16 @@ def main():
     install_shims()
     torch.set_num_threads(8)
     keys = {}
+    if "--only-ragged" in sys.argv:
+        # ---- tiny geometry, ragged targets: frames with 0 / 4 / 1 / 2 valid lanes (empty-target branch of
+        # loss4OLV3.py:45-48, a full 4x4 assignment, memory made of the mean token only) -------------------------
+        g = O.Geometry(img_h=64, img_w=160, arch="resnet18")
+        model, _ = build_reference(g)
+        out = {}
+        run_train(model, g, len(RAGGED_COUNTS), "train", out, counts=RAGGED_COUNTS)
+        np.savez_compressed(os.path.join(HERE, "tiny_ragged_r18_64x160.npz"), **out)
+        print("tiny ragged", out["train_loss"], out["train_frame_loss"].tolist(), out["train_matched"].tolist())
+        return
     # ---- tiny geometry: every tensor kept ------------------------------------------------------------
     g = O.Geometry(img_h=64, img_w=160, arch="resnet18")
     model, keys["resnet18"] = build_reference(g)

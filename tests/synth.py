@@ -183,9 +183,10 @@ def make_clip(g: O.Geometry, T: int, seed: int = 3407) -> torch.Tensor:
     return torch.from_numpy(r.standard_normal((T, 3, g.img_h, g.img_w), dtype=np.float32))
 
 
-def make_targets(g: O.Geometry, T: int, n_lanes: int = 3, max_lanes_in_label: int = 4) -> torch.Tensor:
+def make_targets(g: O.Geometry, T: int, n_lanes: int = 3, max_lanes_in_label: int = 4, counts=None) -> torch.Tensor:
     """Straight synthetic lanes in the label layout of libs/dataset/openlane/transforms.py:264-297:
-    [neg flag, pos flag, start_y, start_x/(W-1), theta, len/n_strips, xs in pixels (bottom->top), -1e5 invalid]."""
+    [neg flag, pos flag, start_y, start_x/(W-1), theta, len/n_strips, xs in pixels (bottom->top), -1e5 invalid].
+    counts (optional, length T): number of valid lanes per frame (ragged clips: 0 .. max_lanes_in_label)."""
     S, W, H = g.num_points, g.img_w, g.img_h
     strip = H / g.n_strips
     out = np.full((T, max_lanes_in_label, 6 + S), -1e5, dtype=np.float32)
@@ -193,7 +194,7 @@ def make_targets(g: O.Geometry, T: int, n_lanes: int = 3, max_lanes_in_label: in
     out[:, :, 1] = 0
     x0s, slopes = (0.2, 0.45, 0.7, 0.85), (4.0, 0.5, -4.0, -6.0)
     for t in range(T):
-        for j in range(min(n_lanes, max_lanes_in_label)):
+        for j in range(min(n_lanes if counts is None else int(counts[t]), max_lanes_in_label)):
             xs = x0s[j] * W + 5.0 * t + slopes[j] * np.arange(S)
             valid = (xs >= 0) & (xs < W)
             n = int(np.argmin(valid)) if not valid.all() else S

@@ -99,13 +99,13 @@ def _record_heads(model):
     return rec, lambda: (setattr(det, "forward", det_fwd), setattr(crit, "forward", crit_fwd))
 
 
-def _train_case(g, T, gold_file, grad_names_file, grad_rtol=2e-2, grad_rms_atol=5e-3):
+def _train_case(g, T, gold_file, grad_names_file, grad_rtol=2e-2, grad_rms_atol=5e-3, counts=None):
     gold = _gold(gold_file)
     names = json.load(open(os.path.join(GOLD, grad_names_file)))
     model = _build(g)
     model.train()
     rec, undo = _record_heads(model)
-    frames, lanes = synth.make_clip(g, T).cuda(), synth.make_targets(g, T).cuda()
+    frames, lanes = synth.make_clip(g, T).cuda(), synth.make_targets(g, T, counts=counts).cuda()
     loss = model({"frame": frames, "lanes": lanes})
     loss.backward()
     torch.cuda.synchronize()
@@ -180,6 +180,16 @@ def _eval_case(g, T, gold_file, pts_atol=ACT_TOL):
 
 def test_tiny_train_parity_vs_reference_goldens():
     _train_case(O.Geometry(img_h=64, img_w=160, arch="resnet18"), 3, "tiny_r18_64x160.npz", "grad_names_resnet18.json")
+
+
+def test_tiny_ragged_targets_parity_vs_reference_goldens():
+    """Frames with 0 / 4 / 1 / 2 valid lanes (tests/golden/make_goldens.py --only-ragged, produced by the reference): the
+    criterion's empty-target branch (loss4OLV3.py:45-48), a full 4-lane assignment, memory tokens without positives -
+    matched indices exact, per-frame losses, gates, lines, BatchNorm statistics and gradient norms (5e-3) at the tolerances of
+    the regular tiny case; sampled gradient entries to 2 % of the tensor's RMS entry (one more frame of cascade than the
+    regular case: the routing-gate filters see 0.7 % there)."""
+    _train_case(O.Geometry(img_h=64, img_w=160, arch="resnet18"), 4, "tiny_ragged_r18_64x160.npz", "grad_names_resnet18.json",
+                grad_rms_atol=2e-2, counts=(0, 4, 1, 2))
 
 
 def test_tiny_eval_parity_vs_reference_goldens():

@@ -31,14 +31,14 @@ def _load(name):
     return dict(np.load(os.path.join(GOLD, name)))
 
 
-def _train(g, T):
+def _train(g, T, counts=None):
     sd = synth.make_state(g)
     for k, v in sd.items():
         if v.is_floating_point() and "running" not in k and k.split(".")[-1] not in (
                 "prior_feat_ys", "prior_ys", "priors", "priors_on_featmap"):
             v.requires_grad_(True)
     col = {}
-    loss = O.clip_forward(sd, synth.make_clip(g, T), synth.make_targets(g, T), g, training=True,
+    loss = O.clip_forward(sd, synth.make_clip(g, T), synth.make_targets(g, T, counts=counts), g, training=True,
                           track_running_stats=True, collect=col)
     loss.backward()
     return sd, loss, col
@@ -104,6 +104,19 @@ def test_tiny_train_matches_reference():
     names = json.load(open(os.path.join(GOLD, "grad_names_resnet18.json")))
     sd, loss, col = _train(g, 3)
     _check_train(gold, sd, loss, col, g, names, full=True)
+
+
+def test_tiny_ragged_targets_match_reference():
+    """Frames with 0 / 4 / 1 / 2 valid lanes (make_goldens.py --only-ragged): the empty-target branch of the criterion
+    (loss4OLV3.py:45-48: classification term only), a full 4-lane assignment, memory tokens without positives."""
+    g = O.Geometry(img_h=64, img_w=160, arch="resnet18")
+    gold = _load("tiny_ragged_r18_64x160.npz")
+    names = json.load(open(os.path.join(GOLD, "grad_names_resnet18.json")))
+    counts = (0, 4, 1, 2)
+    sd, loss, col = _train(g, len(counts), counts=counts)
+    assert [len([i for i in gold["train_matched"][t, 0] if i >= 0]) for t in range(4)] == list(counts)
+    _check_train(gold, sd, loss, col, g, names, full=False)
+    np.testing.assert_allclose(col["frame_loss"], gold["train_frame_loss"], rtol=1e-3)     # frame 0: classification term only
 
 
 def test_tiny_eval_matches_reference():
