@@ -236,6 +236,17 @@ def main():
     install_shims()
     torch.set_num_threads(8)
     keys = {}
+    if "--only-long" in sys.argv:
+        # ---- tiny geometry, 11-frame eval clip: three frames past the memory depth (save_freq_max = 8), so the FIFO of
+        # saveMemory4Test (Router4OL.py:563-584) drops its oldest entries ---------------------------------------------
+        g = O.Geometry(img_h=64, img_w=160, arch="resnet18")
+        model, _ = build_reference(g)
+        out = {}
+        run_eval(model, g, 11, "eval", out)
+        out["eval_lines"] = out["eval_lines"].astype(np.float32)
+        np.savez_compressed(os.path.join(HERE, "tiny_long_eval_r18_64x160.npz"), **out)
+        print("tiny long eval", out["eval_keep"].tolist())
+        return
     if "--only-ragged" in sys.argv:
         # ---- tiny geometry, ragged targets: frames with 0 / 4 / 1 / 2 valid lanes (empty-target branch of
         # loss4OLV3.py:45-48, a full 4x4 assignment, memory made of the mean token only) -------------------------

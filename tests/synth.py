@@ -195,7 +195,7 @@ def make_targets(g: O.Geometry, T: int, n_lanes: int = 3, max_lanes_in_label: in
     x0s, slopes = (0.2, 0.45, 0.7, 0.85), (4.0, 0.5, -4.0, -6.0)
     for t in range(T):
         for j in range(min(n_lanes if counts is None else int(counts[t]), max_lanes_in_label)):
-            xs = x0s[j] * W + 5.0 * t + slopes[j] * np.arange(S)
+            xs = x0s[j] * W + 5.0 * (t % 8) + slopes[j] * np.arange(S)          # (t % 8: long clips stay inside the tiny image)
             valid = (xs >= 0) & (xs < W)
             n = int(np.argmin(valid)) if not valid.all() else S
             n = min(n, S - 4 - j)

@@ -192,6 +192,12 @@ def test_tiny_ragged_targets_parity_vs_reference_goldens():
                 grad_rms_atol=2e-2, counts=(0, 4, 1, 2))
 
 
+def test_tiny_eleven_frame_eval_parity_vs_reference_goldens():
+    """Eval clip three frames longer than the memory depth (save_freq_max = 8): FIFO of the memory tokens against the
+    reference's own output (tests/golden/make_goldens.py --only-long)."""
+    _eval_case(O.Geometry(img_h=64, img_w=160, arch="resnet18"), 11, "tiny_long_eval_r18_64x160.npz")
+
+
 def test_tiny_eval_parity_vs_reference_goldens():
     _eval_case(O.Geometry(img_h=64, img_w=160, arch="resnet18"), 4, "tiny_r18_64x160.npz")
 

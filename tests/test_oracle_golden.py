@@ -119,6 +119,12 @@ def test_tiny_ragged_targets_match_reference():
     np.testing.assert_allclose(col["frame_loss"], gold["train_frame_loss"], rtol=1e-3)     # frame 0: classification term only
 
 
+def test_tiny_eleven_frame_eval_matches_reference():
+    """Three frames past the memory depth (save_freq_max = 8): the FIFO of saveMemory4Test drops its oldest entries
+    (make_goldens.py --only-long, produced by the reference)."""
+    _check_eval(_load("tiny_long_eval_r18_64x160.npz"), O.Geometry(img_h=64, img_w=160, arch="resnet18"), 11)
+
+
 def test_tiny_eval_matches_reference():
     _check_eval(_load("tiny_r18_64x160.npz"), O.Geometry(img_h=64, img_w=160, arch="resnet18"), 4)
 
