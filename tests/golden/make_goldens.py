@@ -236,6 +236,18 @@ def main():
     install_shims()
     torch.set_num_threads(8)
     keys = {}
+    if "--only-config4" in sys.argv:
+        # ---- BASELINE.json configs[3] geometry: 10-frame clip 3x384x960 (its DLA-34 backbone does not exist in the reference
+        # - ResNet-34 instead): other feature-map sizes (12x30 .. 48x120) and a TRAINING clip longer than the memory depth ----
+        g = O.Geometry(img_h=384, img_w=960, arch="resnet34")
+        model, _ = build_reference(g)
+        out = {}
+        run_train(model, g, 10, "train", out, keep_preds=False)
+        run_eval(model, g, 10, "eval", out)
+        out["eval_lines"] = out["eval_lines"].astype(np.float32)
+        np.savez_compressed(os.path.join(HERE, "config4_r34_384x960.npz"), **out)
+        print("config4", out["train_loss"], out["train_frame_loss"].tolist(), out["eval_keep"].tolist())
+        return
     if "--only-long" in sys.argv:
         # ---- tiny geometry, 11-frame eval clip: three frames past the memory depth (save_freq_max = 8), so the FIFO of
         # saveMemory4Test (Router4OL.py:563-584) drops its oldest entries ---------------------------------------------

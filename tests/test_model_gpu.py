@@ -99,7 +99,7 @@ def _record_heads(model):
     return rec, lambda: (setattr(det, "forward", det_fwd), setattr(crit, "forward", crit_fwd))
 
 
-def _train_case(g, T, gold_file, grad_names_file, grad_rtol=2e-2, grad_rms_atol=5e-3, counts=None):
+def _train_case(g, T, gold_file, grad_names_file, grad_rtol=2e-2, grad_rms_atol=5e-3, counts=None, router_norm_rtol=5e-3):
     gold = _gold(gold_file)
     names = json.load(open(os.path.join(GOLD, grad_names_file)))
     model = _build(g)
@@ -139,7 +139,9 @@ def _train_case(g, T, gold_file, grad_names_file, grad_rtol=2e-2, grad_rms_atol=
         got = float(gr.double().norm())
         rel = abs(got - ref) / (ref + 1e-6)
         worst = max(worst, rel)
-        assert rel <= 5e-3 or abs(got - ref) <= 1e-5, (k, got, ref)
+        assert rel <= (router_norm_rtol if k.startswith("detNet.router.") else 5e-3) or abs(got - ref) <= 1e-5, (k, got, ref)
+        if k.startswith("detNet.router.") and router_norm_rtol > 5e-3:
+            continue        # the sampled entries of a gate tensor belong to ONE anchor: a flipped anchor replaces them wholesale
         head = gr.flatten()[:4].double().cpu().numpy()
         # leading entries: relative, or a fraction of the tensor's RMS entry
         np.testing.assert_allclose(head, gold["train_grad_head"][i][:len(head)], rtol=grad_rtol,
@@ -231,6 +233,19 @@ def test_config2_clip_r34_train_parity():
     # docstring (norms are still held to 5e-3); entries are compared at 5 % / 10 % of the tensor's RMS entry
     _train_case(O.Geometry(arch="resnet34"), 5, "config2_r34_320x800.npz", "grad_names_resnet34.json",
                 grad_rtol=5e-2, grad_rms_atol=1e-1)
+
+
+def test_config4_geometry_ten_frame_clip_parity():
+    """BASELINE.json configs[3] geometry: 10-frame clip 3x384x960 (ResNet-34: the reference has no DLA-34), training clip longer
+    than the memory depth, feature maps 12x30 .. 48x120 - against the reference's own output
+    (tests/golden/make_goldens.py --only-config4); tolerances of the config-2 case, except the gradient norms of the routing
+    gate's own parameters: the gate ends in sigmoid(relu(.)) (Router.py:45-48), so ONE anchor whose pre-activation sits within
+    rounding noise of zero switches its whole gradient path on or off - over 30 gate evaluations that moves a gate
+    parameter's gradient norm by up to 2 % here (5e-2 allowed; every other parameter: 5e-3)."""
+    g = O.Geometry(img_h=384, img_w=960, arch="resnet34")
+    _train_case(g, 10, "config4_r34_384x960.npz", "grad_names_resnet34.json", grad_rtol=5e-2, grad_rms_atol=1e-1,
+                router_norm_rtol=5e-2)
+    _eval_case(g, 10, "config4_r34_384x960.npz")
 
 
 def test_config2_clip_r34_eval_parity():

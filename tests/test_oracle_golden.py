@@ -148,3 +148,22 @@ def test_config2_clip_r34_train_and_eval():
     sd, loss, col = _train(g, 5)
     _check_train(gold, sd, loss, col, g, names, full=False)
     _check_eval(gold, g, 5)
+
+
+def test_config4_geometry_ten_frame_clip_eval():
+    """BASELINE.json configs[3] geometry (10 frames 3x384x960; ResNet-34 because the reference has no DLA-34): feature maps
+    12x30 .. 48x120, eval clip longer than the memory depth, against the reference's own output
+    (make_goldens.py --only-config4)."""
+    _check_eval(_load("config4_r34_384x960.npz"), O.Geometry(img_h=384, img_w=960, arch="resnet34"), 10)
+
+
+@pytest.mark.skipif(os.environ.get("PHNET_SLOW_TESTS") != "1", reason="5 minutes of CPU: set PHNET_SLOW_TESTS=1 (passes; the GPU "
+                    "suite holds the HIP path to the same fixture on every run)")
+def test_config4_geometry_ten_frame_clip_train():
+    """The same geometry, TRAINING clip longer than the memory depth (FIFO of saveMemory, Router4OL.py:563-584)."""
+    g = O.Geometry(img_h=384, img_w=960, arch="resnet34")
+    gold = _load("config4_r34_384x960.npz")
+    names = json.load(open(os.path.join(GOLD, "grad_names_resnet34.json")))
+    sd, loss, col = _train(g, 10)
+    _check_train(gold, sd, loss, col, g, names, full=False)
+    np.testing.assert_allclose(col["frame_loss"], gold["train_frame_loss"], rtol=1e-3)
