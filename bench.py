@@ -314,7 +314,7 @@ def main():
         batched = None
         if world == 1 and CB == 1 and args.batched_extra > 1 and use_graph:
             batched = batched_extra(args)
-        out = {"metric": "clips/s (5x3x320x800) fwd+bwd", "value": round(world * CB * args.steps / dt, 4), "unit": "clips/s",
+        out = {"metric": f"clips/s ({T}x3x{args.height}x{args.width}) fwd+bwd", "value": round(world * CB * args.steps / dt, 4), "unit": "clips/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f32" if args.mma == "f32" else "f32 storage and accumulation, bf16x2-split MFMA inputs", "data": "synthetic",
