@@ -498,9 +498,12 @@ def memory_tokens(attn_feats: Sequence[Tensor], positives: Sequence[Tensor]) -> 
 
 
 def clip_forward(sd: State, frames: Tensor, lanes: Optional[Tensor], g: Geometry, training: bool,
-                 nms_fn=None, track_running_stats: bool = False, collect: Optional[dict] = None):
-    """frames [T,3,H,W]; lanes [T,L,6+S] (train).  Train: summed loss over frames.  Eval: per-frame decode dicts."""
-    feats = fpn_neck(sd, resnet_trunk(sd, frames, g, training, track_running_stats))
+                 nms_fn=None, track_running_stats: bool = False, collect: Optional[dict] = None, feats=None):
+    """frames [T,3,H,W]; lanes [T,L,6+S] (train).  Train: summed loss over frames.  Eval: per-frame decode dicts.
+    feats (optional): this clip's pyramid maps computed elsewhere - the slice of a trunk pass over the frames of several
+    clips, i.e. data-parallel ranks with SyncBatchNorm (trainOL.py:141) seen from one rank."""
+    if feats is None:
+        feats = fpn_neck(sd, resnet_trunk(sd, frames, g, training, track_running_stats))
     memory: List[List[Tensor]] = []
     total = 0.0
     decoded = []

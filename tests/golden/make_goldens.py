@@ -228,6 +228,64 @@ def run_eval(model, g, T, tag, out):
     out[f"{tag}_lane_npts"], out[f"{tag}_lane_pts"], out[f"{tag}_lane_meta"] = npts, pts, meta
 
 
+PAIR_SEEDS = (3407, 3408)
+
+
+def run_pair(model, g, T, out):
+    """Two clips as two data-parallel ranks with SyncBatchNorm (trainOL.py:141: convert_sync_batchnorm + DDP), emulated in
+    one CPU process with the reference's own modules only: the trunk runs ONCE over the frames of both clips (= batch
+    statistics over both ranks, and their backward), then each clip goes through RouterOL.forward with a stub in place of
+    the trunk that hands out the clip's slice of those feature maps; the SUM of the two clip losses is back-propagated
+    (DDP would average: a factor 1/2 on every gradient)."""
+    clips = [synth.make_clip(g, T, seed=s) for s in PAIR_SEEDS]
+    lanes = synth.make_targets(g, T)
+    model.train()
+    model.zero_grad()
+    enc = model.backbone
+    feats = enc(torch.cat(clips))
+
+    class Slice(nn.Module):
+        def __init__(self, lo):
+            super().__init__()
+            self.lo = lo
+
+        def forward(self, x):
+            return tuple(f[self.lo:self.lo + T] for f in feats)
+
+    rec = {"matched": [], "frame_loss": []}
+    crit = model.criterion
+    crit_fwd = crit.forward
+
+    def crit_hook(o, gt, diff=None):
+        m, l = crit_fwd(o, gt, diff)
+        rec["matched"].append([np.asarray(x, dtype=np.int64) for x in m])
+        rec["frame_loss"].append(float(l.detach()))
+        return m, l
+    crit.forward = crit_hook
+    losses = []
+    for b, fr in enumerate(clips):
+        model.backbone = Slice(b * T)
+        losses.append(model({"frame": fr, "lanes": lanes}))
+    model.backbone = enc
+    crit.forward = crit_fwd
+    total = losses[0] + losses[1]
+    total.backward()
+    names, norms, heads = grad_digest(model)
+    out["pair_loss"] = np.float64(total.item())
+    out["pair_clip_loss"] = np.array([float(l.item()) for l in losses])
+    out["pair_frame_loss"] = np.array(rec["frame_loss"]).reshape(2, T)
+    mm = np.full((2, T, 3, g.max_lanes), -1, dtype=np.int64)
+    for i, per in enumerate(rec["matched"]):
+        for s_, idx in enumerate(per):
+            mm[i // T, i % T, s_, :len(idx)] = idx
+    out["pair_matched"] = mm
+    out["pair_grad_norm"], out["pair_grad_head"] = norms, heads
+    bn = model.backbone.backbone.model.bn1
+    out["pair_bn1_running_mean"] = bn.running_mean.numpy().copy()
+    out["pair_bn1_running_var"] = bn.running_var.numpy().copy()
+    return names
+
+
 def strided_digest(t: torch.Tensor):
     return t[..., ::4, ::5].numpy().copy(), t.double().sum(dim=(2, 3)).numpy()
 
@@ -236,6 +294,16 @@ def main():
     install_shims()
     torch.set_num_threads(8)
     keys = {}
+    if "--only-pair" in sys.argv:
+        # ---- tiny geometry, two clips = two data-parallel ranks with SyncBatchNorm (BASELINE.json configs[2] semantics) ----
+        g = O.Geometry(img_h=64, img_w=160, arch="resnet18")
+        model, _ = build_reference(g)
+        out = {}
+        names = run_pair(model, g, 3, out)
+        assert names == json.load(open(os.path.join(HERE, "grad_names_resnet18.json")))
+        np.savez_compressed(os.path.join(HERE, "tiny_pair_syncbn_r18_64x160.npz"), **out)
+        print("tiny pair", out["pair_loss"], out["pair_clip_loss"].tolist(), out["pair_matched"][:, 0].tolist())
+        return
     if "--only-config4" in sys.argv:
         # ---- BASELINE.json configs[3] geometry: 10-frame clip 3x384x960 (its DLA-34 backbone does not exist in the reference
         # - ResNet-34 instead): other feature-map sizes (12x30 .. 48x120) and a TRAINING clip longer than the memory depth ----

@@ -529,6 +529,49 @@ def test_training_batched_over_clips_equals_clip_by_clip():
         assert abs(ga[k] - gb[k]) <= tol * ga[k] + 1e-5, (k, ga[k], gb[k])
 
 
+def test_two_clips_per_step_equal_two_reference_ranks_with_syncbn():
+    """BASELINE.json configs[2] semantics: B clips per step with joint BatchNorm statistics = B data-parallel ranks with
+    SyncBatchNorm (trainOL.py:141).  Fixture from the reference's own modules (tests/golden/make_goldens.py --only-pair: its
+    trunk run once over the frames of both clips, head and criterion per clip, summed loss): summed and per-frame losses,
+    matched indices (exact), BatchNorm running statistics and per-parameter gradient norms of `model([2,T,3,H,W])`."""
+    g = O.Geometry(img_h=64, img_w=160, arch="resnet18")
+    gold = _gold("tiny_pair_syncbn_r18_64x160.npz")
+    names = json.load(open(os.path.join(GOLD, "grad_names_resnet18.json")))
+    T = 3
+    model = _build(g)
+    model.train()
+    rec = {"matched": [], "loss": []}
+    crit = model.criterion
+    crit_fwd = crit.forward
+
+    def hook(o, gt, diff=None):
+        m, l = crit_fwd(o, gt, diff)
+        rec["matched"].append([[i for i in x.cpu().tolist() if i >= 0] for x in m])
+        rec["loss"].append(float(l.detach()))
+        return m, l
+    crit.forward = hook
+    frames = torch.stack([synth.make_clip(g, T, seed=s) for s in (3407, 3408)]).cuda()
+    lanes = torch.stack([synth.make_targets(g, T)] * 2).cuda()
+    loss = model({"frame": frames, "lanes": lanes})
+    loss.backward()
+    torch.cuda.synchronize()
+    crit.forward = crit_fwd
+    assert abs(loss.item() - gold["pair_loss"]) <= ACT_TOL * abs(gold["pair_loss"])
+    for t in range(T):                                       # the criterion is called clip by clip inside every frame index
+        for b in range(2):
+            i = t * 2 + b
+            assert abs(rec["loss"][i] - gold["pair_frame_loss"][b, t]) <= ACT_TOL * abs(gold["pair_frame_loss"][b, t]), (b, t)
+            for s_ in range(3):
+                assert rec["matched"][i][s_] == [j for j in gold["pair_matched"][b, t, s_].tolist() if j >= 0], (b, t, s_)
+    bn = model.backbone.backbone.model.bn1
+    _close(bn.running_mean, gold["pair_bn1_running_mean"], 1e-4, "bn1 running mean")
+    _close(bn.running_var, gold["pair_bn1_running_var"], 1e-4, "bn1 running var")
+    params = dict(model.named_parameters())
+    for i, k in enumerate(names):
+        ref, got = float(gold["pair_grad_norm"][i]), float(params[k].grad.double().norm())
+        assert abs(got - ref) <= (5e-2 if k.startswith("detNet.router.") else 5e-3) * ref + 1e-5, (k, got, ref)
+
+
 def test_arena_direct_accumulation_equals_autograd_accumulation():
     """Gradients accumulated by the HIP kernels straight into the flat arena == autograd's own accumulation."""
     from phnet_amd.arena import GradArena

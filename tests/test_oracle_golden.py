@@ -167,3 +167,40 @@ def test_config4_geometry_ten_frame_clip_train():
     sd, loss, col = _train(g, 10)
     _check_train(gold, sd, loss, col, g, names, full=False)
     np.testing.assert_allclose(col["frame_loss"], gold["train_frame_loss"], rtol=1e-3)
+
+
+@pytest.mark.skipif(os.environ.get("PHNET_SLOW_TESTS") != "1", reason="1.5 minutes of CPU: set PHNET_SLOW_TESTS=1 (passes; the GPU "
+                    "suite holds the HIP path to the same fixture on every run)")
+def test_tiny_pair_of_clips_with_joint_batchnorm_statistics():
+    """Two clips = two data-parallel ranks with SyncBatchNorm (make_goldens.py --only-pair: the reference's trunk run once over
+    the frames of both clips, its head and criterion per clip, summed loss)."""
+    g = O.Geometry(img_h=64, img_w=160, arch="resnet18")
+    gold = _load("tiny_pair_syncbn_r18_64x160.npz")
+    names = json.load(open(os.path.join(GOLD, "grad_names_resnet18.json")))
+    T = 3
+    sd = synth.make_state(g)
+    for k, v in sd.items():
+        if v.is_floating_point() and "running" not in k and k.split(".")[-1] not in (
+                "prior_feat_ys", "prior_ys", "priors", "priors_on_featmap"):
+            v.requires_grad_(True)
+    clips = [synth.make_clip(g, T, seed=s) for s in (3407, 3408)]
+    feats = O.fpn_neck(sd, O.resnet_trunk(sd, torch.cat(clips), g, True, True))
+    total, cols = 0.0, []
+    for b, fr in enumerate(clips):
+        col = {}
+        total = total + O.clip_forward(sd, fr, synth.make_targets(g, T), g, training=True, collect=col,
+                                       feats=[f[b * T:(b + 1) * T] for f in feats])
+        cols.append(col)
+    total.backward()
+    assert abs(total.item() - gold["pair_loss"]) <= 5e-4 * abs(gold["pair_loss"])
+    for b in range(2):
+        np.testing.assert_allclose(cols[b]["frame_loss"], gold["pair_frame_loss"][b], rtol=1e-3)
+        for t in range(T):
+            for s_ in range(3):
+                assert cols[b]["positives"][t][s_].tolist() == [i for i in gold["pair_matched"][b, t, s_].tolist() if i >= 0]
+    np.testing.assert_allclose(sd["backbone.backbone.model.bn1.running_mean"].numpy(), gold["pair_bn1_running_mean"], atol=1e-6)
+    np.testing.assert_allclose(sd["backbone.backbone.model.bn1.running_var"].numpy(), gold["pair_bn1_running_var"], rtol=1e-5)
+    for i, k in enumerate(names):
+        ref = gold["pair_grad_norm"][i]
+        got = float(sd[k].grad.double().norm())
+        assert abs(got - ref) <= 3e-3 * ref + 1e-6, (k, got, ref)
