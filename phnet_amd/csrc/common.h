@@ -14,16 +14,34 @@ static inline int phnet_launch_status() {
     return hipGetLastError() == hipSuccess ? PHNET_OK : PHNET_ERR_LAUNCH;
 }
 
+// Wave-wide reductions on the DPP data path (quad swaps, row rotations, row broadcasts - the rocPRIM sequence): six
+// VALU instructions with a DPP modifier and one v_readlane instead of six ds_bpermute round trips through the LDS pipeline
+// (~100 cycles each, and the LayerNorm-heavy kernels chain dozens of them).  All 64 lanes must be active; the total is
+// returned to every lane.
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+    const int i = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, CTRL, 0xf, 0xf, false));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    v += dpp_move<0xb1>(v);        // quad_perm [1,0,3,2]
+    v += dpp_move<0x4e>(v);        // quad_perm [2,3,0,1]
+    v += dpp_move<0x124>(v);       // row_ror 4
+    v += dpp_move<0x128>(v);       // row_ror 8
+    v += dpp_move<0x142>(v);       // row_bcast 15
+    v += dpp_move<0x143>(v);       // row_bcast 31: lane 63 now holds the sum of all 64 lanes
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-    return v;
+    v = fmaxf(v, dpp_move<0xb1>(v));
+    v = fmaxf(v, dpp_move<0x4e>(v));
+    v = fmaxf(v, dpp_move<0x124>(v));
+    v = fmaxf(v, dpp_move<0x128>(v));
+    v = fmaxf(v, dpp_move<0x142>(v));
+    v = fmaxf(v, dpp_move<0x143>(v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 // ---- counter-based dropout masks --------------------------------------------------------------------------------
