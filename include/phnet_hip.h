@@ -242,9 +242,10 @@ int phnet_blend_priors(const float* gate, const float* a, const float* b, const 
 
 /* ---- optimizer: one AdamW step (torch.optim.AdamW semantics, libs/utils/optimizer.py:33-35) over flat parameter / gradient /
  * moment arrays; elements [0, n_decay) get decoupled weight decay.  n % 4 == 0.  step: device int64, 1-based, already
- * incremented by the caller for this step. ---- */
+ * incremented by the caller for this step.  lr_dev (optional): DEVICE pointer to the learning rate; when non-NULL it
+ * replaces `lr`, so that a hipGraph-captured step follows an LR schedule (the host rewrites the scalar between replays). ---- */
 int phnet_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, int64_t n_decay, const int64_t* step,
-                     float lr, float beta1, float beta2, float eps, float weight_decay, void* stream);
+                     float lr, const float* lr_dev, float beta1, float beta2, float eps, float weight_decay, void* stream);
 
 /* residual + dropout + LayerNorm of the pre-norm decoder layers in one launch: t = res + dropout(x), h = LN_L(t)*w + b
  * (L <= 256), and its backward (dt = gradient arriving on the residual stream, may be NULL): dres, dx, dw, db. */

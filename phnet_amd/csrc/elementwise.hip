@@ -52,10 +52,11 @@ __global__ __launch_bounds__(NT) void gelu_dropout_bwd_kernel(const float* __res
 //   p *= 1 - lr*wd;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= (lr / (1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
 __global__ __launch_bounds__(NT) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, long n4, long n_decay, const long long* __restrict__ step,
-                                                   float lr, float b1, float b2, float eps, float wd)
+                                                   float lr, const float* __restrict__ lr_dev, float b1, float b2, float eps, float wd)
 {
     const long i = (long)blockIdx.x * NT + threadIdx.x;
     if (i >= n4) return;
+    if (lr_dev) lr = lr_dev[0];                      // learning rate from device memory: a replayed hipGraph follows the schedule
     const float t = (float)step[0];
     const float c1 = 1.0f - powf(b1, t), c2s = sqrtf(1.0f - powf(b2, t));
     const float step_size = lr / c1;
@@ -374,14 +375,15 @@ PHNET_API int phnet_blend_priors(const float* gate, const float* a, const float*
 
 // One AdamW step over flat fp32 arrays (n % 4 == 0, 16-byte aligned); elements [0, n_decay) get decoupled weight decay.
 // step: DEVICE pointer to the 1-based step count as int64 (the caller increments it before the call - part of the captured
-// step, so replays advance the bias correction).
+// step, so replays advance the bias correction).  lr_dev (optional DEVICE pointer to one float): when given, the learning
+// rate is read from it and `lr` is ignored - the host updates that scalar between replays of a captured step.
 PHNET_API int phnet_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, int64_t n_decay, const int64_t* step,
-                               float lr, float beta1, float beta2, float eps, float weight_decay, void* stream)
+                               float lr, const float* lr_dev, float beta1, float beta2, float eps, float weight_decay, void* stream)
 {
     if (n < 0 || (n & 3) || n_decay < 0 || n_decay > n) return PHNET_ERR_ARG;
     if (n == 0) return PHNET_OK;
     if (!p || !g || !m || !v || !step) return PHNET_ERR_ARG;
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)ceil_div64(n / 4, NT)), dim3(NT), 0, (hipStream_t)stream, p, g, m, v, (long)(n / 4),
-                       (long)n_decay, (const long long*)step, lr, beta1, beta2, eps, weight_decay);
+                       (long)n_decay, (const long long*)step, lr, lr_dev, beta1, beta2, eps, weight_decay);
     return phnet_launch_status();
 }

@@ -66,6 +66,8 @@ class GraphedTrainStep:
         self.frames.copy_(frames, non_blocking=True)
         if lanes is not None:
             self.lanes.copy_(lanes, non_blocking=True)
+        if hasattr(self.optimizer, "sync_lr"):
+            self.optimizer.sync_lr()                    # LR schedule -> the device scalar the captured AdamW launch reads
         self.graph.replay()
         if self.graph_opt is not None:
             self.between()

@@ -630,15 +630,18 @@ def blend_priors(gate, a, b, idx):
     return priors, on_map
 
 
-def adamw_step(p, g, m, v, n_decay: int, step, lr: float, beta1: float, beta2: float, eps: float, weight_decay: float):
-    """In-place AdamW over flat fp32 buffers (all the same length, a multiple of 4); step = int64[1] device tensor."""
+def adamw_step(p, g, m, v, n_decay: int, step, lr: float, beta1: float, beta2: float, eps: float, weight_decay: float, lr_dev=None):
+    """In-place AdamW over flat fp32 buffers (all the same length, a multiple of 4); step = int64[1] device tensor.
+    lr_dev (optional float32[1] device tensor) replaces `lr` (read on the device: capturable LR schedules)."""
     for t, name in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
         _req(t, name=name)
     _req(step, torch.int64, "step")
     if not (p.numel() == g.numel() == m.numel() == v.numel()):
         raise ValueError("adamw_step: p/g/m/v lengths differ")
-    check(lib().phnet_adamw_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), int(n_decay), _ptr(step), float(lr), float(beta1),
-                                 float(beta2), float(eps), float(weight_decay), _stream()), "phnet_adamw_step")
+    if lr_dev is not None:
+        _req(lr_dev, name="lr_dev")
+    check(lib().phnet_adamw_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), int(n_decay), _ptr(step), float(lr), _ptr(lr_dev),
+                                 float(beta1), float(beta2), float(eps), float(weight_decay), _stream()), "phnet_adamw_step")
 
 
 def dropout_add(x, res=None, rng=None):

@@ -546,6 +546,39 @@ def test_flat_adamw_matches_torch_adamw(ops):
             for (k, a), b in zip(ref.named_parameters(), net.parameters()):
                 close(b, a, 2e-6)
         assert int(fopt.step_count) == 4
+        # the caller step of the reference around it: per-iteration cosine schedule (trainOL.py:121-124,228) and GradScaler
+        # (trainOL.py:225-227); the last two steps replay ONE captured optimizer launch - the schedule reaches it through lr_dev
+        tsch = torch.optim.lr_scheduler.CosineAnnealingLR(topt, T_max=10, eta_min=1e-5)
+        fsch = torch.optim.lr_scheduler.CosineAnnealingLR(fopt, T_max=10, eta_min=1e-5)
+        scaler = torch.amp.GradScaler("cuda", init_scale=65536.0)
+        graph = None
+        for step in range(5):
+            x = torch.randn(5, 8, 8, 8, device="cuda")
+            topt.zero_grad(set_to_none=True)
+            fopt.zero_grad()
+            ref(x).square().mean().backward()
+            if step < 2:                                              # eager, through the GradScaler
+                scaler.scale(net(x).square().mean()).backward()
+                scaler.step(fopt)
+                scaler.update()
+            else:
+                net(x).square().mean().backward()
+                if graph is None:
+                    st = torch.cuda.Stream()
+                    st.wait_stream(torch.cuda.current_stream())
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.stream(st):
+                        with torch.cuda.graph(graph, stream=st):
+                            fopt.step()
+                    torch.cuda.current_stream().wait_stream(st)
+                fopt.sync_lr()
+                graph.replay()
+            topt.step()
+            tsch.step(); fsch.step()
+            assert abs(fopt.param_groups[0]["lr"] - topt.param_groups[0]["lr"]) < 1e-12
+            for (k, a), b in zip(ref.named_parameters(), net.parameters()):
+                close(b, a, 5e-6)
+        assert int(fopt.step_count) == 9
     finally:
         arena.release()
 
