@@ -742,7 +742,10 @@ ConvPlan plan_conv(long M, int Co, int K, bool has_ws, size_t ws_bytes)
     }
     ConvPlan p{t.bm, t.bn, 1, ceil_div64(M, t.bm) * ceil_div64(Co, t.bn)};
     // split K until ~1250 workgroups are in flight (about 5 per CU), keeping >= 256 of K per split
-    if (has_ws && p.tiles < 900) {
+    // K-tile-64 plans (M <= 2048: the head GEMMs) hold 70 KB of LDS per workgroup = 2 workgroups per CU, so ~512 tiles already
+    // fill the chip in one round and a split only adds the reduce pass (hyper-net 1024 -> 8192 at 240 rows: 54 vs 62 us)
+    const bool deep = M <= 2048 && K >= 64;
+    if (has_ws && p.tiles < (deep ? 400 : 900)) {
         int splits = (int)min((long)8, max((long)1, (1250 + p.tiles / 2) / p.tiles));
         while (splits > 1 && K / splits < 256) --splits;
         while (splits > 1 && (size_t)splits * M * Co * sizeof(float) > ws_bytes) --splits;

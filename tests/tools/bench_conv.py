@@ -44,7 +44,10 @@ def main():
     if "--mma" in sys.argv:
         assert lib().phnet_tune_mma(1) == 0
         print("split-bf16 arithmetic")
+    only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None
     for name, N, Hi, Wi, Ci, Co, R, st, pad in (SHAPES[:4] if TRUNK_ONLY else SHAPES):
+        if only and only not in name:
+            continue
         N *= CLIPS
         x = torch.randn(N, Hi, Wi, Ci, device="cuda"); w = torch.randn(Co, R, R, Ci, device="cuda") * 0.05
         ho, wo = K.conv_out_hw(Hi, Wi, R, R, st, pad)
