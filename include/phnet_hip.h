@@ -126,6 +126,17 @@ int phnet_bn_bwd_apply(const float* dy, const float* x, const float* y, const fl
                        const float* gamma, const float* c1, const float* c2, float* dx, float* dres,
                        int64_t M, int32_t C, int32_t relu, int32_t dres_accumulate, void* stream);
 
+/* device-resident SyncBatchNorm (trainOL.py:141): no host read of the element count, so the step stays sync-free.
+ * fwd: phnet_bn_local_sums -> all-reduce(SUM) sums[2C+1] (fp64: sum x, sum x^2, count) -> phnet_bn_finalize_sums -> phnet_bn_apply
+ * bwd: phnet_bn_bwd_reduce -> all-reduce(SUM) sums[2][C] -> phnet_bn_bwd_apply_sums (count = &sums_fwd[2C]) */
+int phnet_bn_local_sums(const float* x, int64_t M, int32_t C, float* partial, double* sums, void* stream);
+int phnet_bn_finalize_sums(const double* sums, int32_t C, float eps, float momentum, const float* gamma, const float* beta,
+                           float* running_mean, float* running_var, float* save_mean, float* save_invstd,
+                           float* scale, float* shift, void* stream);
+int phnet_bn_bwd_apply_sums(const float* dy, const float* x, const float* y, const float* mean, const float* invstd,
+                            const float* gamma, const float* sums, const double* count, float* c1, float* c2,
+                            float* dx, float* dres, int64_t M, int32_t C, int32_t relu, int32_t dres_accumulate, void* stream);
+
 /* ---- MaxPool2d(3,2,1): libs/models/resnet.py:217,297 ---- */
 int phnet_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* argmax, int32_t N, int32_t Hi, int32_t Wi, int32_t C, void* stream);
 int phnet_maxpool3x3s2_bwd(const float* dy, const uint8_t* argmax, float* dx, int32_t N, int32_t Hi, int32_t Wi, int32_t C, void* stream);

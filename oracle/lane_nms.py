@@ -54,8 +54,13 @@ def lane_nms_sorted(rows: np.ndarray, order: np.ndarray, thresh: float, top_k: i
 
 
 def score_order(scores: np.ndarray) -> np.ndarray:
-    """Descending score order (csrc/nms.cpp:51); ties (unspecified in the reference) by lower index."""
-    return np.argsort(-np.asarray(scores, dtype=np.float32), kind="stable").astype(np.int64)
+    """Descending score order (csrc/nms.cpp:51); ties (unspecified in the reference) by lower index; a NaN score sorts
+    above every number (ATen's sort treats NaN as the largest value), NaNs among themselves by index."""
+    s = np.asarray(scores, dtype=np.float32)
+    nan = np.isnan(s)
+    with np.errstate(invalid="ignore"):
+        key = np.where(nan, np.float32(0), -s)
+    return np.lexsort((np.arange(s.size), key, ~nan)).astype(np.int64)       # primary: NaN first; then -score; then index
 
 
 def lane_nms(rows, scores, overlap: float, top_k: int):

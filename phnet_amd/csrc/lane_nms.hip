@@ -49,13 +49,19 @@ __device__ __forceinline__ int nms_core(const float* R, const float* scores, int
 {
     const int tid = threadIdx.x;
     const int words = (K + 63) >> 6;
-    // ---- rank by descending score (ties: lower index first) ----
+    // ---- rank by descending score (ties: lower index first).  The order must be TOTAL or two rows share a rank and a slot
+    // of order[] stays unwritten: a NaN score ranks above every number, as in the reference's scores.sort(0, descending=True)
+    // (csrc/nms.cpp:51: ATen orders NaN as the largest value), NaNs among themselves by index ----
     for (int i = tid; i < K; i += NMS_THREADS) {
         const float si = scores[i];
+        const bool ni = si != si;
         int rank = 0;
         for (int j = 0; j < K; ++j) {
             const float sj = scores[j];
-            rank += (sj > si) || (sj == si && j < i);
+            const bool nj = sj != sj;
+            const bool above = (nj && !ni) || (sj > si);
+            const bool tied = (nj && ni) || (sj == si);
+            rank += above || (tied && j < i);
         }
         order[rank] = i;
     }

@@ -178,6 +178,65 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(
     }
 }
 
+// ---- cross-rank (SyncBatchNorm) pieces: everything stays on the device, the caller only all-reduces two small buffers ----
+// sums [2C+1] fp64 = (sum x [C], sum x^2 [C], element count) of THIS rank: additive across ranks
+__global__ __launch_bounds__(NT) void bn_local_sums_kernel(const float* __restrict__ partial, int nblk, long M, int C,
+                                                           double* __restrict__ sums)
+{
+    const int c = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (c >= C) return;
+    double s = 0.0, ss = 0.0;
+    for (int b = lane; b < nblk; b += 64) {
+        s += (double)partial[(size_t)b * 2 * C + c];
+        ss += (double)partial[(size_t)b * 2 * C + C + c];
+    }
+    s = wave_sum_f64(s);
+    ss = wave_sum_f64(ss);
+    if (lane == 0) {
+        sums[c] = s;
+        sums[C + c] = ss;
+        if (c == 0) sums[2 * C] = (double)M;
+    }
+}
+
+// (all-reduced) sums -> statistics of the union batch, running statistics (unbiased variance with the GLOBAL count, like
+// torch.nn.SyncBatchNorm), scale / shift.  The count is read from device memory: no host round trip.
+__global__ __launch_bounds__(NT) void bn_finalize_sums_kernel(
+    const double* __restrict__ sums, int C, float eps, float momentum, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ running_mean, float* __restrict__ running_var,
+    float* __restrict__ save_mean, float* __restrict__ save_invstd, float* __restrict__ scale, float* __restrict__ shift)
+{
+    const int c = blockIdx.x * NT + threadIdx.x;
+    if (c >= C) return;
+    const double n = sums[2 * C];
+    const double mu = sums[c] / n;
+    double var = sums[C + c] / n - mu * mu;
+    var = var < 0.0 ? 0.0 : var;
+    const float mean = (float)mu, invstd = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+    save_mean[c] = mean;
+    save_invstd[c] = invstd;
+    const float sc = gamma[c] * invstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - mean * sc;
+}
+
+// c1 = sum_g / count, c2 = sum_g_xhat / count from the (all-reduced) f32 sums [2][C] = (sum g*xhat, sum g) and the device count
+__global__ __launch_bounds__(NT) void bn_bwd_means_kernel(const float* __restrict__ sums, const double* __restrict__ count, int C,
+                                                          float* __restrict__ c1, float* __restrict__ c2)
+{
+    const int c = blockIdx.x * NT + threadIdx.x;
+    if (c >= C) return;
+    const double n = *count;
+    c1[c] = (float)((double)sums[C + c] / n);
+    c2[c] = (float)((double)sums[c] / n);
+}
+
 // ---- max pool 3x3 / stride 2 / pad 1, NHWC ---------------------------------------------------------------
 __global__ __launch_bounds__(NT) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                          unsigned char* __restrict__ arg, int N, int Hi, int Wi, int C,
@@ -420,6 +479,51 @@ PHNET_API int phnet_bn_bwd_apply(const float* dy, const float* x, const float* y
     const long total4 = M * C / 4;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)ceil_div64(total4, NT)), dim3(NT), 0, (hipStream_t)stream,
                        dy, x, y, mean, invstd, gamma, c1, c2, dx, dres, total4, C, relu, dres_accumulate);
+    return phnet_launch_status();
+}
+
+// ---- SyncBatchNorm forward, device-resident (trainOL.py:141 nn.SyncBatchNorm.convert_sync_batchnorm) -------------------------
+// step 1: sums [2C+1] fp64 = (sum x, sum x^2, count M) of this rank -> the caller all-reduces (SUM) the buffer across ranks
+PHNET_API int phnet_bn_local_sums(const float* x, int64_t M, int32_t C, float* partial, double* sums, void* stream)
+{
+    if (M < 1 || !channels_ok(C) || !x || !partial || !sums) return PHNET_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    long rpb;
+    const int nblk = (int)stat_blocks(M, &rpb);
+    hipLaunchKernelGGL(channel_partials_kernel<0>, dim3(nblk), dim3(NT), 2 * NT * sizeof(f32x4), st,
+                       x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                       partial, (long)M, C, rpb, 0);
+    hipLaunchKernelGGL(bn_local_sums_kernel, dim3((C + 3) / 4), dim3(NT), 0, st, (const float*)partial, nblk, (long)M, C, sums);
+    return phnet_launch_status();
+}
+
+// step 2: reduced sums -> save_mean / save_invstd / scale / shift (+ running statistics).  Then phnet_bn_apply as usual.
+PHNET_API int phnet_bn_finalize_sums(const double* sums, int32_t C, float eps, float momentum, const float* gamma, const float* beta,
+                                     float* running_mean, float* running_var, float* save_mean, float* save_invstd,
+                                     float* scale, float* shift, void* stream)
+{
+    if (!channels_ok(C) || !sums || !gamma || !beta || !save_mean || !save_invstd || !scale || !shift ||
+        (!running_mean != !running_var))
+        return PHNET_ERR_ARG;
+    hipLaunchKernelGGL(bn_finalize_sums_kernel, dim3((C + NT - 1) / NT), dim3(NT), 0, (hipStream_t)stream, sums, C, eps, momentum,
+                       gamma, beta, running_mean, running_var, save_mean, save_invstd, scale, shift);
+    return phnet_launch_status();
+}
+
+// SyncBatchNorm backward, step 2 with the element count in device memory: sums [2][C] f32 = all-reduced (sum g*xhat, sum g)
+// from phnet_bn_bwd_reduce, count = the all-reduced sums[2C] of the forward.  c1 / c2: [C] scratch.
+PHNET_API int phnet_bn_bwd_apply_sums(const float* dy, const float* x, const float* y, const float* mean, const float* invstd,
+                                      const float* gamma, const float* sums, const double* count, float* c1, float* c2,
+                                      float* dx, float* dres, int64_t M, int32_t C, int32_t relu, int32_t dres_accumulate,
+                                      void* stream)
+{
+    if (M < 1 || !channels_ok(C) || !dy || !x || !mean || !invstd || !gamma || !sums || !count || !c1 || !c2 || !dx || (relu && !y))
+        return PHNET_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_bwd_means_kernel, dim3((C + NT - 1) / NT), dim3(NT), 0, st, sums, count, C, c1, c2);
+    const long total4 = M * C / 4;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)ceil_div64(total4, NT)), dim3(NT), 0, st,
+                       dy, x, y, mean, invstd, gamma, (const float*)c1, (const float*)c2, dx, dres, total4, C, relu, dres_accumulate);
     return phnet_launch_status();
 }
 

@@ -2,8 +2,11 @@
 
 The per-clip step is ~20 000 small launches (15 serial stage iterations); replaying them from a hipGraph removes the
 host from the loop.  Works because the training path is shape-static and sync-free (device-side label assignment,
-fixed-capacity memory tokens).  With data parallelism the gradient all-reduce runs eagerly between two graphs
-(forward+backward | optimizer).
+fixed-capacity memory tokens).  With data parallelism the RCCL collectives - SyncBatchNorm exchanges (device-resident
+counts: nothing is read on the host), gradient buckets overlapped with the trunk's backward - are captured in the same
+graph.  (Measured on this stack, ROCm 7.0 / RCCL 2.26 / torch 2.10: an RCCL all-reduce captures and replays fine; issuing
+collectives EAGERLY between captured segments does not work - the process group's watchdog thread polls the events of
+those eager collectives while the next segment is being captured and dies with hipErrorCapturedEvent.)
 
 Capture caveat (PyTorch, not ours): autograd graphs of earlier EAGER steps on the default stream must be dead before a
 step is captured - a loss / gradient tensor that is still referenced keeps AccumulateGrad nodes bound to the default
@@ -13,12 +16,44 @@ from typing import Callable, Optional
 import torch
 
 
+def data_parallel_step(model, arena, reducer, optimizer, frames, lanes, loss_divisor: float, stage_done=None):
+    """One data-parallel training step, eagerly or under hipGraph capture:
+    zero | trunk forward (staged, SyncBatchNorm exchanges inside) + lane head + loss | head backward | bucket 0 out |
+    trunk backward, further buckets as its stages finish | wait | optimizer.  `loss_divisor` includes the world size: the
+    buckets are SUM-reduced."""
+    enc = model.backbone
+
+    def done(part: str):
+        i = arena.bucket_of_part.get(part)
+        if i is not None:
+            reducer.issue(i)
+        if stage_done is not None:
+            stage_done(part)
+    arena.zero()
+    enc.staged = True
+    try:
+        loss = model({"frame": frames, "lanes": lanes}) / loss_divisor
+        loss.backward()
+        enc.finish_backward(done)
+    finally:
+        enc.staged = False
+    reducer.finish()
+    optimizer.step()
+    return loss.detach()
+
+
 class GraphedTrainStep:
     def __init__(self, model: torch.nn.Module, optimizer: torch.optim.Optimizer, frames: torch.Tensor, lanes: torch.Tensor,
-                 loss_divisor: Optional[float] = None, warmup: int = 3, arena=None, between: Optional[Callable[[], None]] = None):
-        """between: optional callable run eagerly between backward and the optimizer step (the data-parallel gradient
-        all-reduce); the step is then recorded as two graphs (forward+backward | optimizer) around it."""
-        self.model, self.optimizer, self.arena, self.between = model, optimizer, arena, between
+                 loss_divisor: Optional[float] = None, warmup: int = 3, arena=None, between: Optional[Callable[[], None]] = None,
+                 reducer=None):
+        """reducer (parallel.BucketReducer over `arena`): data-parallel step - staged trunk (phnet_amd/trunk.py), gradient
+        buckets all-reduced while the trunk's backward still runs, SyncBatchNorm exchanges where the model has
+        nn.SyncBatchNorm containers; the whole step, collectives included, is ONE hipGraph (needs a backend whose
+        collectives can be stream-captured: RCCL; with gloo run data_parallel_step eagerly).  loss_divisor should then
+        include the world size (the buckets are SUM-reduced).
+        between (older form): a callable run eagerly between backward and the optimizer step; the step is recorded as two
+        graphs (forward+backward | optimizer) around it."""
+        self.model, self.optimizer, self.arena, self.between, self.reducer = model, optimizer, arena, between, reducer
         self.frames, self.lanes = frames.clone(), lanes.clone()
         self.div = float(loss_divisor if loss_divisor is not None else frames.shape[0])
         side = torch.cuda.Stream()
@@ -32,7 +67,15 @@ class GraphedTrainStep:
         self.graph_opt = None
         if arena is None:
             optimizer.zero_grad(set_to_none=True)
-        if between is None:
+        if reducer is not None:
+            if arena is None or not hasattr(arena, "bucket_of_part"):
+                raise ValueError("GraphedTrainStep(reducer=...) needs the arena of FlatAdamW.for_model(backward_order=True)")
+            # ONE graph for the whole data-parallel step, the RCCL collectives captured inside it (the asynchronous bucket
+            # all-reduces become parallel branches of the graph next to the trunk's backward).  thread_local: the watchdog
+            # thread of torch.distributed polls events while we capture.
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                self.loss = self._step()
+        elif between is None:
             with torch.cuda.graph(self.graph):
                 self.loss = self._step(zero=arena is not None)
         else:
@@ -56,6 +99,8 @@ class GraphedTrainStep:
         return loss.detach()
 
     def _step(self, zero: bool = True):
+        if self.reducer is not None:
+            return data_parallel_step(self.model, self.arena, self.reducer, self.optimizer, self.frames, self.lanes, self.div)
         loss = self._fwd_bwd(zero)
         if self.between is not None:
             self.between()

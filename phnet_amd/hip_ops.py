@@ -62,11 +62,19 @@ def _req(t: torch.Tensor, dtype=torch.float32, name="tensor"):
     return t
 
 
+_WS_RETIRED = []
+
+
 def workspace(nbytes: int, device, slot: int = 0) -> torch.Tensor:
-    """Grow-only scratch buffer per (device, slot).  Kernels on one stream serialise, so sharing is safe."""
+    """Grow-only scratch buffer per (device, slot).  Kernels on one stream serialise, so sharing is safe.
+    A buffer that is outgrown is RETIRED, never freed: a captured hipGraph may hold its address (split-K partials,
+    BatchNorm partials, LayerNorm scratch), and handing that memory back to the caching allocator would let a later replay
+    scribble over tensors that reuse it.  (A few MB per growth step, a handful of steps per process.)"""
     key = (torch.device(device).index, slot)
     cur = _WS.get(key)
     if cur is None or cur.numel() < nbytes:
+        if cur is not None:
+            _WS_RETIRED.append(cur)
         cur = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         _WS[key] = cur
     return cur
@@ -131,11 +139,14 @@ def conv2d_fwd(x, w, bias, stride: int, pad: int, relu: bool = False, out: Optio
     ho, wo = conv_out_hw(hi, wi, r, s, stride, pad)
     if out is None:
         out = torch.empty((n, ho, wo, co), dtype=torch.float32, device=x.device)
-    ws = workspace(8 * n * ho * wo * co * 4 if n * ho * wo * co < (1 << 23) else 0, x.device)
+    # split-K scratch: the plan (csrc/conv.hip plan_conv) sees the size THIS shape asks for, not whatever the shared buffer
+    # has grown to - the same shape always runs the same plan, whatever ran before it in the process
+    need = 8 * n * ho * wo * co * 4 if n * ho * wo * co < (1 << 23) else 0
+    ws = workspace(need, x.device) if need else None
     m, k = n * ho * wo, r * s * ci
-    _timed_launch(lambda: _gemm_symbol(m, co, k, ws.numel(), False, ci), 2.0 * m * co * k,
+    _timed_launch(lambda: _gemm_symbol(m, co, k, need, False, ci), 2.0 * m * co * k,
                   lambda: check(lib().phnet_conv2d_fwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(out), n, hi, wi, ci, co, r, s, stride,
-                                                       pad, int(relu), _ptr(ws), ws.numel(), _stream()), "phnet_conv2d_fwd"))
+                                                       pad, int(relu), _ptr(ws), need, _stream()), "phnet_conv2d_fwd"))
     return out
 
 
@@ -145,11 +156,12 @@ def conv2d_dgrad(dy, w, in_hw: Tuple[int, int], stride: int, pad: int, addend: O
     co, r, s, ci = w.shape
     hi, wi = in_hw
     dx = torch.empty((n, hi, wi, ci), dtype=torch.float32, device=dy.device)
-    ws = workspace(8 * n * hi * wi * ci * 4 if n * hi * wi * ci < (1 << 23) else 0, dy.device)
+    need = 8 * n * hi * wi * ci * 4 if n * hi * wi * ci < (1 << 23) else 0
+    ws = workspace(need, dy.device) if need else None
     m, k = n * hi * wi, r * s * co
-    _timed_launch(lambda: _gemm_symbol(m, ci, k, ws.numel(), True, co), 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * co * r * s * ci,
+    _timed_launch(lambda: _gemm_symbol(m, ci, k, need, True, co), 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * co * r * s * ci,
                   lambda: check(lib().phnet_conv2d_dgrad(_ptr(dy), _ptr(w), _ptr(addend), _ptr(dx), n, hi, wi, ci, co, r, s, stride,
-                                                         pad, _ptr(ws), ws.numel(), _stream()), "phnet_conv2d_dgrad"))
+                                                         pad, _ptr(ws), need, _stream()), "phnet_conv2d_dgrad"))
     return dx
 
 
@@ -164,7 +176,7 @@ def conv2d_wgrad(dy, x, w_shape, stride: int, pad: int, dw: Optional[torch.Tenso
         dw = torch.empty((co, r, s, ci), dtype=torch.float32, device=x.device)
         assert not accumulate
     need = lib().phnet_conv2d_wgrad_workspace(n, hi, wi, ci, co, r, s, stride, pad)
-    ws = workspace(need, x.device)
+    ws = workspace(need, x.device) if need else None
     ho, wo = conv_out_hw(hi, wi, r, s, stride, pad)
     smallp = (r == 1 and s == 1 and stride == 1 and pad == 0 and n * ho * wo <= 256 and
               ((co + 63) // 64) * ((ci + 63) // 64) < 400)                                # few-rows Linear kernel (csrc/conv.hip)
@@ -172,7 +184,7 @@ def conv2d_wgrad(dy, x, w_shape, stride: int, pad: int, dw: Optional[torch.Tenso
                            else f"conv_wgrad_kernel<{128 if (co >= 128 and (co < 256 or n * ho * wo > 8192)) else 64}, 64, {_MMA_MODE}>", 0),
                   2.0 * n * ho * wo * co * r * s * ci,
                   lambda: check(lib().phnet_conv2d_wgrad(_ptr(dy), _ptr(x), _ptr(dw), _ptr(dbias), n, hi, wi, ci, co, r, s, stride,
-                                                         pad, int(accumulate), _ptr(ws), ws.numel(), _stream()), "phnet_conv2d_wgrad"))
+                                                         pad, int(accumulate), _ptr(ws), need, _stream()), "phnet_conv2d_wgrad"))
     return dw
 
 
@@ -259,9 +271,10 @@ def bn_fwd(x, gamma, beta, running_mean, running_var, training: bool, eps: float
 
 
 def bn_bwd(dy, x, y, save_mean, save_invstd, gamma, relu: bool, dres: Optional[torch.Tensor] = None,
-           dres_accumulate: bool = False, dgamma: Optional[torch.Tensor] = None, dbeta: Optional[torch.Tensor] = None):
+           dres_accumulate: bool = False, dgamma: Optional[torch.Tensor] = None, dbeta: Optional[torch.Tensor] = None,
+           param_accumulate: bool = False):
     """Returns (dx, dgamma, dbeta); writes/accumulates the residual-branch gradient into dres when given.
-    dgamma/dbeta may be caller-provided destinations (overwritten)."""
+    dgamma/dbeta may be caller-provided destinations: overwritten, or added to with param_accumulate (gradient arena)."""
     _req(dy, name="dy")
     c = x.shape[-1]
     m = x.numel() // c
@@ -273,43 +286,41 @@ def bn_bwd(dy, x, y, save_mean, save_invstd, gamma, relu: bool, dres: Optional[t
     part = _partials(m, c, dev)
     check(lib().phnet_bn_bwd(_ptr(dy), _ptr(x), _ptr(y), _ptr(save_mean), _ptr(save_invstd), _ptr(gamma), _ptr(dx),
                              _ptr(dres), _ptr(dgamma), _ptr(dbeta), _ptr(part), _ptr(c12[0]), _ptr(c12[1]),
-                             m, c, int(relu), int(dres_accumulate), 0, _stream()), "phnet_bn_bwd")
+                             m, c, int(relu), int(dres_accumulate), int(param_accumulate), _stream()), "phnet_bn_bwd")
     return dx, dgamma, dbeta
 
 
 def bn_fwd_sync(x, gamma, beta, running_mean, running_var, eps: float, momentum: float, residual=None, relu: bool = True,
                 group=None):
-    """Training-mode BatchNorm whose statistics are merged across the ranks of `group` (SyncBatchNorm,
-    trainOL.py:141): local (mean, var) from the statistics kernel -> one fp64 all-reduce -> global scale/shift."""
+    """Training-mode BatchNorm whose statistics span the ranks of `group` (nn.SyncBatchNorm, trainOL.py:141), without any
+    host round trip: local fp64 (sum x, sum x^2, count) -> ONE all-reduce of 2C+1 doubles -> statistics of the union batch,
+    running statistics, scale / shift on the device.  Returns (y, mean, invstd, count) with `count` a device view (fp64[1])
+    of the reduced element count, which the backward reads on the device too."""
     from . import parallel
     _req(x, name="x")
     c = x.shape[-1]
     m = x.numel() // c
     dev = x.device
-    scale = torch.empty(c, dtype=torch.float32, device=dev)
-    shift = torch.empty(c, dtype=torch.float32, device=dev)
-    sm = torch.empty(c, dtype=torch.float32, device=dev)
-    si = torch.empty(c, dtype=torch.float32, device=dev)
+    stats = torch.empty(4, c, dtype=torch.float32, device=dev)          # mean, invstd, scale, shift
+    sums = torch.empty(2 * c + 1, dtype=torch.float64, device=dev)
     part = _partials(m, c, dev)
-    check(lib().phnet_bn_fwd_stats(_ptr(x), m, c, eps, momentum, _ptr(gamma), _ptr(beta), None, None, _ptr(sm), _ptr(si),
-                                   _ptr(scale), _ptr(shift), _ptr(part), 1, _stream()), "phnet_bn_fwd_stats")
-    var_local = (1.0 / si.double() ** 2 - eps).clamp_min(0.0).float()
-    g_mean, g_var, total = parallel.merge_batch_statistics(sm, var_local, m, group)
-    g_invstd = torch.rsqrt(g_var + eps)
-    if running_mean is not None:
-        running_mean.mul_(1 - momentum).add_(g_mean, alpha=momentum)
-        running_var.mul_(1 - momentum).add_(g_var * (total / max(total - 1, 1)), alpha=momentum)
-    scale = gamma * g_invstd
-    shift = beta - g_mean * scale
+    check(lib().phnet_bn_local_sums(_ptr(x), m, c, _ptr(part), _ptr(sums), _stream()), "phnet_bn_local_sums")
+    parallel.allreduce_sum_(sums, group)
+    check(lib().phnet_bn_finalize_sums(_ptr(sums), c, eps, momentum, _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
+                                       _ptr(stats[0]), _ptr(stats[1]), _ptr(stats[2]), _ptr(stats[3]), _stream()), "phnet_bn_finalize_sums")
     y = torch.empty_like(x)
-    check(lib().phnet_bn_apply(_ptr(x), _ptr(scale.contiguous()), _ptr(shift.contiguous()), _ptr(residual), _ptr(y), m, c,
-                               int(relu), _stream()), "phnet_bn_apply")
-    return y, g_mean.contiguous(), g_invstd.contiguous(), total
+    check(lib().phnet_bn_apply(_ptr(x), _ptr(stats[2]), _ptr(stats[3]), _ptr(residual), _ptr(y), m, c, int(relu), _stream()),
+          "phnet_bn_apply")
+    return y, stats[0], stats[1], sums[2 * c:]
 
 
-def bn_bwd_sync(dy, x, y, mean, invstd, gamma, relu: bool, total: int, dres: Optional[torch.Tensor] = None, group=None):
-    """SyncBatchNorm backward: local (sum g*xhat, sum g) -> all-reduce -> dx with the global means; dgamma/dbeta stay
-    local (DDP averages parameter gradients afterwards), as torch.nn.SyncBatchNorm does."""
+def bn_bwd_sync(dy, x, y, mean, invstd, gamma, relu: bool, count, dres: Optional[torch.Tensor] = None, group=None,
+                dres_accumulate: bool = False, dgamma: Optional[torch.Tensor] = None, dbeta: Optional[torch.Tensor] = None,
+                param_accumulate: bool = False):
+    """SyncBatchNorm backward: local (sum g*xhat, sum g) -> ONE all-reduce of 2C floats -> dx with the global means (count is
+    the device scalar of the forward).  dgamma / dbeta stay LOCAL sums (the gradient averaging across ranks treats them like
+    every other parameter gradient, as with torch.nn.SyncBatchNorm under DDP); they are written / added to the given
+    destinations."""
     from . import parallel
     _req(dy, name="dy")
     c = x.shape[-1]
@@ -320,12 +331,17 @@ def bn_bwd_sync(dy, x, y, mean, invstd, gamma, relu: bool, total: int, dres: Opt
     part = _partials(m, c, dev)
     check(lib().phnet_bn_bwd_reduce(_ptr(dy), _ptr(x), _ptr(y), _ptr(mean), _ptr(invstd), _ptr(sums), _ptr(part),
                                     _ptr(scratch[0]), _ptr(scratch[1]), m, c, int(relu), _stream()), "phnet_bn_bwd_reduce")
-    dgamma, dbeta = sums[0].clone(), sums[1].clone()
-    g = parallel.allreduce_sum_(sums.double(), group)
-    c2, c1 = (g[0] / total).float().contiguous(), (g[1] / total).float().contiguous()
+    if dgamma is None:
+        dgamma, dbeta = sums[0].clone(), sums[1].clone()
+    elif param_accumulate:
+        dgamma.add_(sums[0]); dbeta.add_(sums[1])
+    else:
+        dgamma.copy_(sums[0]); dbeta.copy_(sums[1])
+    parallel.allreduce_sum_(sums, group)
     dx = torch.empty_like(x)
-    check(lib().phnet_bn_bwd_apply(_ptr(dy), _ptr(x), _ptr(y), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(c1), _ptr(c2),
-                                   _ptr(dx), _ptr(dres), m, c, int(relu), 0, _stream()), "phnet_bn_bwd_apply")
+    check(lib().phnet_bn_bwd_apply_sums(_ptr(dy), _ptr(x), _ptr(y), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(sums), _ptr(count),
+                                        _ptr(scratch[0]), _ptr(scratch[1]), _ptr(dx), _ptr(dres), m, c, int(relu),
+                                        int(dres_accumulate), _stream()), "phnet_bn_bwd_apply_sums")
     return dx, dgamma, dbeta
 
 

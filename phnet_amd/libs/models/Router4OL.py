@@ -43,6 +43,13 @@ class Encoder(nn.Module):
         self.neck = FPN(**cfg.neck) if cfg.haskey("neck") else None
         if self.neck is None:
             raise NotImplementedError("the hot path needs the FPN neck (options4OL.py:58-61)")
+        self.staged = False                     # True: forward outside autograd + finish_backward() (phnet_amd/trunk.py, graphed.py)
+        self._staged = None
+
+    def finish_backward(self, stage_done=None):
+        """Staged mode only: the trunk's backward, to be called after the lane head's `loss.backward()`."""
+        from phnet_amd.trunk import encoder_backward_staged
+        encoder_backward_staged(self, stage_done)
 
     def forward(self, batch):
         frames = batch["img"] if isinstance(batch, dict) else batch
@@ -345,9 +352,17 @@ class RouterOL(nn.Module):
         self.batch_stage0 = True        # stage-0 ROI pooling / dynamic head / branch A of all frames in one batch
 
     def _begin_clip(self):
-        self.detNet._branch_cache = None                                       # weights may have changed since the last clip
-        for head in self.detNet.DHead_series:
+        det = self.detNet
+        det._branch_cache = None                                               # weights may have changed since the last clip
+        for head in det.DHead_series:
             head.begin_clip()
+        # the anchors expanded from the embeddings are kept on the module (as in the reference, Router4OL.py:258-259) - but
+        # without their autograd history: a graph that outlives its step keeps AccumulateGrad nodes bound to that step's
+        # stream, and a later hipGraph capture on another stream then faults (PyTorch: "AccumulateGrad node's stream does
+        # not match")
+        if det.priors.grad_fn is not None:
+            det.priors = det.priors.detach()
+            det.priors_on_featmap = det.priors_on_featmap.detach()
 
     def infer_device(self, frame: torch.Tensor):
         """Eval forward of one clip without any host synchronisation (hipGraph-capturable): returns

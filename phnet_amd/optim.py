@@ -8,13 +8,27 @@ from typing import Iterable, Sequence, Tuple
 import torch
 
 from . import hip_ops as K
-from .arena import GradArena
+from .arena import GradArena, _view_like
 
 
 def split_decay(params: Iterable[torch.nn.Parameter]) -> Tuple[list, list]:
     """(decayed, not decayed): 1-D parameters - biases, normalisation affine - carry no weight decay."""
     params = [p for p in params if p.requires_grad]
     return [p for p in params if p.dim() > 1], [p for p in params if p.dim() <= 1]
+
+
+def model_part(param_name: str) -> int:
+    """Index into phnet_amd.trunk.PARTS of the part of RouterOL a parameter belongs to (by its state_dict name)."""
+    if param_name.startswith("module."):                      # DistributedDataParallel wrapper
+        param_name = param_name[len("module."):]
+    if not param_name.startswith("backbone."):
+        return 0                                               # detNet.* (the lane head) and anything that is not the encoder
+    if param_name.startswith("backbone.neck."):
+        return 1
+    for i, stage in enumerate(("layer4", "layer3", "layer2", "layer1")):
+        if f".{stage}." in param_name:
+            return 2 + i
+    return 6                                                   # conv1 / bn1
 
 
 class FlatAdamW(torch.optim.Optimizer):
@@ -29,7 +43,8 @@ class FlatAdamW(torch.optim.Optimizer):
         if arena.flat_params is None:
             raise ValueError("FlatAdamW needs GradArena(..., flatten_params=True)")
         self.arena, self.n_decay = arena, int(n_decay)
-        self.betas, self.eps, self.weight_decay = (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
+        self.weight_decay = float(weight_decay)
+        betas, eps = (float(betas[0]), float(betas[1])), float(eps)
         self.exp_avg = torch.zeros_like(arena.flat_params)
         self.exp_avg_sq = torch.zeros_like(arena.flat_params)
         dev = arena.flat_params.device
@@ -42,40 +57,128 @@ class FlatAdamW(torch.optim.Optimizer):
         groups = [{"params": decayed, "weight_decay": self.weight_decay}]
         if rest:
             groups.append({"params": rest, "weight_decay": 0.0})
-        super().__init__(groups, dict(lr=float(lr), betas=self.betas, eps=self.eps, weight_decay=self.weight_decay))
+        super().__init__(groups, dict(lr=float(lr), betas=betas, eps=eps, weight_decay=self.weight_decay))
 
     @classmethod
-    def for_model(cls, model: torch.nn.Module, **kw):
-        """Builds the arena (decayed parameters first) and the optimizer; returns (optimizer, arena)."""
-        decay, no_decay = split_decay(model.parameters())
+    def for_model(cls, model: torch.nn.Module, backward_order: bool = True, **kw):
+        """Builds the arena (decayed parameters first) and the optimizer; returns (optimizer, arena).
+        backward_order: inside the decayed section the parameters are laid out in the order in which the backward pass
+        FINISHES their gradients (lane head, neck, layer4 ... layer1, stem: phnet_amd.trunk.PARTS), and
+        `arena.bucket_bounds` / `arena.bucket_of_part` describe 4 contiguous buckets for parallel.BucketReducer: bucket i can
+        be all-reduced as soon as the part named in bucket_of_part has reported `stage_done` (the 1-D parameters - biases,
+        normalisation affine: 0.3 % of the elements - travel with the last bucket)."""
+        if not backward_order:
+            decay, no_decay = split_decay(model.parameters())
+            arena = GradArena(decay + no_decay, flatten_params=True)
+            return cls(arena, sum(p.numel() for p in decay), **kw), arena
+        named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+        part = {id(p): model_part(n) for n, p in named}
+        decay = sorted([p for _, p in named if p.dim() > 1], key=lambda p: part[id(p)])          # stable: keeps module order inside a part
+        no_decay = sorted([p for _, p in named if p.dim() <= 1], key=lambda p: part[id(p)])
         arena = GradArena(decay + no_decay, flatten_params=True)
-        return cls(arena, sum(p.numel() for p in decay), **kw), arena
+        n_decay = sum(p.numel() for p in decay)
+        ends, off = {}, 0
+        for p in decay:
+            off += p.numel()
+            ends[part[id(p)]] = off
+
+        def end_of(*parts):                                   # end offset of the last non-empty part among `parts`
+            e = [ends[i] for i in parts if i in ends]
+            return max(e) if e else None
+        b1 = end_of(0) or 0                                    # lane head
+        b2 = end_of(1, 2) or b1                                # neck + layer4
+        b3 = end_of(3) or b2                                   # layer3
+        arena.bucket_bounds = [0, b1, b2, b3, arena.flat.numel()]
+        arena.bucket_of_part = {"head": 0, "layer4": 1, "layer3": 2, "stem": 3}
+        return cls(arena, n_decay, **kw), arena
 
     def sync_lr(self):
         """Copies param_groups[0]['lr'] (what LR schedulers write) into the device scalar the kernel reads.  Not capturable:
         call it eagerly (before a graph replay)."""
         self.lr_dev.fill_(float(self.param_groups[0]["lr"]))
 
+    def _hyper(self):
+        """(lr, betas, eps, weight_decay) as the param_groups hold them NOW (schedulers, load_state_dict and user code write
+        there).  The kernel applies ONE decay value to the leading n_decay elements and none to the rest, and one lr / betas /
+        eps to everything - the reference's grouping (libs/utils/optimizer.py:41-55); anything else is refused loudly."""
+        g0 = self.param_groups[0]
+        for g in self.param_groups[1:]:
+            if float(g.get("weight_decay", 0.0)) != 0.0:
+                raise ValueError("FlatAdamW: only the first parameter group may carry weight decay")
+            if float(g["lr"]) != float(g0["lr"]) or tuple(g["betas"]) != tuple(g0["betas"]) or float(g["eps"]) != float(g0["eps"]):
+                raise ValueError("FlatAdamW: all parameter groups must share lr / betas / eps")
+        return float(g0["lr"]), (float(g0["betas"][0]), float(g0["betas"][1])), float(g0["eps"]), float(g0["weight_decay"])
+
     @torch.no_grad()
     def step(self, closure=None):
+        """One launch over the flat arenas.  Difference to torch.optim.AdamW, documented: a parameter whose gradient is all
+        zero (torch: `grad is None`, skipped entirely) still receives its weight decay here - the arena has no notion of
+        'no gradient'; on the reference's path that only concerns the transformer on a one-frame clip."""
         if closure is not None:
             raise ValueError("FlatAdamW.step takes no closure")
+        lr, betas, eps, wd = self._hyper()
         if not torch.cuda.is_current_stream_capturing():
             self.sync_lr()
         self.step_count.add_(1)
         K.adamw_step(self.arena.flat_params, self.arena.flat, self.exp_avg, self.exp_avg_sq, self.n_decay, self.step_count,
-                     float(self.param_groups[0]["lr"]), self.betas[0], self.betas[1], self.eps, self.weight_decay, lr_dev=self.lr_dev)
+                     lr, betas[0], betas[1], eps, wd, lr_dev=self.lr_dev)
 
     def zero_grad(self, set_to_none: bool = False):
         """One memset of the gradient arena; the .grad views stay (set_to_none is ignored: the HIP kernels accumulate into them)."""
         self.arena.zero()
 
+    # ---- checkpoints: torch.optim.AdamW's own layout, so the reference's resume path works both ways
+    # (trainOL.py:128 `optimizer.load_state_dict(checkpoint['optimizer'])`, :182 `'optimizer': optimizer.state_dict()`) ----
+    def _param_slices(self):
+        """[(index in torch's numbering, offset, numel, parameter)]: torch numbers parameters group by group, which is the
+        arena order (decayed first)."""
+        return [(i, *self.arena.offsets[id(p)], p) for i, p in enumerate(self.arena.params)]
+
     def state_dict(self):
-        return {"exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "step": self.step_count,
-                "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
+        step = self.step_count.detach().to(torch.float32).reshape(()).cpu()
+        state = {}
+        for i, off, n, p in self._param_slices():
+            state[i] = {"step": step.clone(),
+                        "exp_avg": _view_like(self.exp_avg[off:off + n], p).clone(),          # logical shape; channels_last
+                        "exp_avg_sq": _view_like(self.exp_avg_sq[off:off + n], p).clone()}   # parameters keep OHWI memory order
+        groups, start = [], 0
+        for g in self.param_groups:
+            d = {k: v for k, v in g.items() if k != "params"}
+            d.setdefault("amsgrad", False)
+            d["params"] = list(range(start, start + len(g["params"])))
+            start += len(g["params"])
+            groups.append(d)
+        return {"state": state, "param_groups": groups}
 
     def load_state_dict(self, sd):
-        self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"]); self.step_count.copy_(sd["step"])
-        for g, saved in zip(self.param_groups, sd["param_groups"]):
-            g.update(saved)
-        self.sync_lr()
+        if "state" not in sd:                                   # round-1 private layout (flat moments)
+            self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"]); self.step_count.copy_(sd["step"])
+            for g, saved in zip(self.param_groups, sd["param_groups"]):
+                g.update({k: v for k, v in saved.items() if k != "params"})
+            self._hyper(); self.sync_lr()
+            return
+        saved_groups = sd["param_groups"]
+        if [len(g["params"]) for g in saved_groups] != [len(g["params"]) for g in self.param_groups]:
+            raise ValueError("FlatAdamW.load_state_dict: parameter groups of the checkpoint do not match this model "
+                             f"({[len(g['params']) for g in saved_groups]} vs {[len(g['params']) for g in self.param_groups]})")
+        order = [i for g in saved_groups for i in g["params"]]   # checkpoint id of our parameter #k
+        self.exp_avg.zero_(); self.exp_avg_sq.zero_()
+        steps = []
+        for (k, off, n, p), cid in zip(self._param_slices(), order):
+            st = sd["state"].get(cid, sd["state"].get(str(cid)))
+            if st is None:                                       # torch keeps no state for parameters that never had a gradient
+                continue
+            if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                raise ValueError(f"FlatAdamW.load_state_dict: state {cid} has shape {tuple(st['exp_avg'].shape)}, parameter {tuple(p.shape)}")
+            if st.get("max_exp_avg_sq") is not None and saved_groups[0].get("amsgrad"):
+                raise ValueError("FlatAdamW: amsgrad checkpoints are not supported")
+            _view_like(self.exp_avg[off:off + n], p).copy_(st["exp_avg"])
+            _view_like(self.exp_avg_sq[off:off + n], p).copy_(st["exp_avg_sq"])
+            steps.append(int(float(st["step"])))
+        if steps and min(steps) != max(steps):
+            raise ValueError("FlatAdamW keeps ONE step counter; the checkpoint's parameters are at different steps "
+                             f"({min(steps)}..{max(steps)})")
+        self.step_count.fill_(steps[0] if steps else 0)
+        for g, saved in zip(self.param_groups, saved_groups):
+            g.update({k: v for k, v in saved.items() if k != "params"})
+        self._hyper(); self.sync_lr()

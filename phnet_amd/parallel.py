@@ -40,7 +40,23 @@ def shard_indices(n_units: int, rank: int, world: int, shuffle_seed: Optional[in
 
 
 def active(group=None) -> bool:
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    """True when collectives have to be issued.  PHNET_FORCE_COLLECTIVES=1 also issues them in a one-rank group (they are
+    identities there): lets a single GPU exercise the real RCCL call path, incl. its coexistence with hipGraph capture."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or os.environ.get("PHNET_FORCE_COLLECTIVES", "0") == "1"
+
+
+# Every collective of the data path goes through run_collective(): a single choke point (tests count the collectives of a
+# step through it).
+_RUNNER = None
+
+
+def run_collective(fn):
+    """fn(): issues torch.distributed call(s) IN PLACE on tensors that outlive the call."""
+    if _RUNNER is not None:
+        return _RUNNER(fn)
+    return fn()
 
 
 def merge_batch_statistics(mean: torch.Tensor, var_biased: torch.Tensor, count: int, group=None):
@@ -60,8 +76,9 @@ def merge_batch_statistics(mean: torch.Tensor, var_biased: torch.Tensor, count: 
 
 
 def allreduce_sum_(t: torch.Tensor, group=None) -> torch.Tensor:
+    """In-place SUM over the ranks (blocking for the STREAM, not the host)."""
     if active(group):
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        run_collective(lambda: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group))
     return t
 
 
@@ -110,3 +127,47 @@ def allreduce_flat_(flat: torch.Tensor, chunks: int = 4, group=None) -> int:
         w.wait()
     flat.div_(world)
     return len(work)
+
+
+class BucketReducer:
+    """Gradient averaging over a flat arena whose element order follows the BACKWARD schedule (phnet_amd/arena.py:
+    backward_order): bucket i is the range [bounds[i], bounds[i+1]) and `issue(i)` starts its asynchronous all-reduce as soon
+    as the backward has written its last element - bucket 0 (the lane head: 77 % of the parameters of ResNet-34) goes out when
+    the trunk's backward starts and hides behind it; the remaining buckets follow the trunk stages.  Few, large collectives:
+    xGMI links are point-to-point, a ring step is per-link bound, so 4 messages of tens of MB beat DDP's 25 MB buckets.
+    SUM reduction: the caller pre-divides the loss by the world size (so that the reduced arena IS the mean gradient)."""
+
+    def __init__(self, flat: torch.Tensor, bounds: List[int], group=None):
+        assert bounds[0] == 0 and bounds[-1] == flat.numel() and all(a <= b for a, b in zip(bounds, bounds[1:])), bounds
+        self.flat, self.bounds, self.group = flat, list(bounds), group
+        self.work = []
+        self.issued = []
+
+    @property
+    def n_buckets(self) -> int:
+        return len(self.bounds) - 1
+
+    def issue(self, i: int):
+        lo, hi = self.bounds[i], self.bounds[i + 1]
+        self.issued.append(i)
+        if hi <= lo or not active(self.group):
+            return
+
+        def go():
+            self.work.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        run_collective(go)
+
+    def finish(self):
+        """Issues whatever has not been issued yet and makes the current stream wait for every bucket."""
+        for i in range(self.n_buckets):
+            if i not in self.issued:
+                self.issue(i)
+        self.issued = []
+        if not active(self.group):
+            return
+
+        def wait():
+            for w in self.work:
+                w.wait()
+            self.work = []
+        run_collective(wait)

@@ -81,3 +81,20 @@ def test_c_matches_numpy_restatement_on_random_lanes(K, n_off, seed):
     a = N.lane_nms(rows, scores, 50.0, 4 if K < 200 else 1000)
     b = N.lane_nms_numpy(rows, scores, 50.0, 4 if K < 200 else 1000)
     assert a[1] == b[1] and a[0].tolist() == b[0].tolist() and a[2].tolist() == b[2].tolist()
+
+
+def test_kat_nan_and_tied_scores_have_a_total_order():
+    """csrc/nms.cpp:51 sorts with ATen, which orders NaN above every number: a NaN-scored row is visited first (and, here,
+    suppresses its near-duplicate); equal scores fall back to the lower index.  A total order is also what keeps the HIP
+    kernel's rank -> row table fully written."""
+    import torch
+    sc = np.array([0.5, np.nan, 0.9, 0.5, np.nan, -np.inf, np.inf], np.float32)
+    order = N.score_order(sc)
+    assert order.tolist() == [1, 4, 6, 2, 0, 3, 5]
+    assert order.tolist() == torch.sort(torch.from_numpy(sc), descending=True, stable=True)[1].tolist()
+    rows = np.stack([row(0.0, 36, np.full(S, 100.0 + 60 * i)) for i in range(7)])
+    rows[0, 5:] = rows[1, 5:] + 1.0                 # row 0 is a near-duplicate of the NaN-scored row 1
+    keep, num, parent = N.lane_nms(rows, sc, 50.0, 4)
+    assert num == 4 and keep.tolist()[:4] == [1, 4, 6, 2] and parent[0] == 1 and parent[1] == 1
+    a = N.lane_nms_numpy(rows, sc, 50.0, 4)
+    assert a[1] == num and a[0].tolist() == keep.tolist() and a[2].tolist() == parent.tolist()

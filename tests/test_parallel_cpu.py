@@ -83,3 +83,71 @@ def test_single_process_is_a_no_op():
     m, v, n = parallel.merge_batch_statistics(torch.ones(4), torch.full((4,), 2.0), 10)
     assert torch.allclose(m, torch.ones(4)) and torch.allclose(v, torch.full((4,), 2.0)) and n == 10
     assert parallel.average_gradients_([torch.nn.Parameter(torch.zeros(2))]) == 0
+
+
+# ---- round 2: the collectives of the overlapped data-parallel step (phnet_amd/parallel.py, tests/dp_workers.py) ---------------
+def test_allreduce_flat_averages_the_arena():
+    from tests import dp_workers as W
+    for n, err in W.run(W.cpu_allreduce_flat):
+        assert n == 4 and err < 1e-4
+
+
+def test_bucket_reducer_sums_every_element_once_whatever_the_issue_order():
+    from tests import dp_workers as W
+    for per_pattern in W.run(W.cpu_bucket_reducer):
+        for err, seen, pending, issued in per_pattern:
+            assert err == 0.0 and pending == 0 and issued == []
+            assert seen == 3 + 1                       # 3 non-empty buckets + the wait, each through run_collective
+
+
+def test_sync_batchnorm_collectives_reproduce_union_batch_statistics_and_gradients():
+    from tests import dp_workers as W
+    for dm, dv, ddx, n in W.run(W.cpu_sync_statistics):
+        assert dm < 1e-12 and dv < 1e-12 and ddx < 1e-6 and n == 7 * 15
+
+
+def test_backward_ordered_arena_and_bucket_bounds():
+    """FlatAdamW.for_model lays the decayed parameters out in the order the backward finishes them and cuts 4 buckets:
+    lane head | neck + layer4 | layer3 | everything else (layer2, layer1, stem, all 1-D parameters, padding)."""
+    import torch
+    from phnet_amd.config import make_cfg
+    from phnet_amd.libs.models.Router4OL import RouterOL
+    from phnet_amd.libs.utils.loss4OLV3 import Criterion4OL
+    from phnet_amd.optim import FlatAdamW, model_part
+    from phnet_amd.trunk import PARTS
+    cfg = make_cfg(img_h=64, img_w=160, arch="resnet18")
+    model = RouterOL(cfg, Criterion4OL(cfg))
+    opt, arena = FlatAdamW.for_model(model)
+    try:
+        names = {id(p): n for n, p in model.named_parameters()}
+        parts = [model_part(names[id(p)]) for p in arena.params]
+        dims = [p.dim() > 1 for p in arena.params]
+        n_dec = sum(dims)
+        assert all(dims[:n_dec]) and not any(dims[n_dec:])                                  # decayed first (FlatAdamW contract)
+        assert parts[:n_dec] == sorted(parts[:n_dec]) and parts[n_dec:] == sorted(parts[n_dec:])
+        b = arena.bucket_bounds
+        assert b[0] == 0 and b[-1] == arena.flat.numel() and b == sorted(b) and len(b) == 5
+        for p in arena.params[:n_dec]:
+            off, n = arena.offsets[id(p)]
+            bucket = max(i for i in range(4) if b[i] <= off)
+            assert off + n <= b[bucket + 1]                                                 # no parameter straddles a bucket
+            want = {0: 0, 1: 1, 2: 1, 3: 2}.get(model_part(names[id(p)]), 3)
+            assert bucket == want, (names[id(p)], bucket, want)
+        assert set(arena.bucket_of_part) <= set(PARTS) and sorted(arena.bucket_of_part.values()) == [0, 1, 2, 3]
+        assert opt.n_decay == sum(p.numel() for p in arena.params[:n_dec])
+        head_share = b[1] / arena.numel
+        assert head_share > 0.5                                                            # the bucket that hides behind the trunk backward
+    finally:
+        arena.release()
+
+
+def test_run_collective_default_and_hook():
+    from phnet_amd import parallel
+    calls = []
+    assert parallel.run_collective(lambda: calls.append("a") or 7) == 7
+    parallel._RUNNER = lambda fn: ("hooked", fn())
+    try:
+        assert parallel.run_collective(lambda: 5) == ("hooked", 5)
+    finally:
+        parallel._RUNNER = None
+    assert calls == ["a"]

@@ -1,0 +1,79 @@
+"""The data-parallel path on a real GPU (-m gpu): two ranks sharing the one MI355X of the box over gloo (a functional
+rehearsal - on a multi-GPU node the same code runs over RCCL/xGMI), and a one-rank RCCL group for the reference's
+SyncBatchNorm + DistributedDataParallel wrapping."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+
+
+def test_two_rank_syncbn_step_equals_reference_pair_fixture():
+    """BASELINE.json configs[2] semantics on two REAL ranks (one clip each): SyncBatchNorm statistics over both ranks
+    (device-resident count, one small all-reduce per layer and direction), 4 gradient buckets issued in backward order.
+    Against tests/golden/tiny_pair_syncbn_r18_64x160.npz (produced by the reference's own modules run over both clips):
+    summed loss, per-frame losses, matched indices (exact), BatchNorm running statistics, per-parameter norms of the
+    SUM-reduced gradient."""
+    _need_gpu()
+    from tests import dp_workers as W
+    gold = dict(np.load(os.path.join(GOLD, "tiny_pair_syncbn_r18_64x160.npz")))
+    names = json.load(open(os.path.join(GOLD, "grad_names_resnet18.json")))
+    res = W.run(W.gpu_two_rank_step_vs_pair_fixture, world=2, backend="gloo")
+    total = sum(r["loss"] for r in res)
+    assert abs(total - gold["pair_loss"]) <= 1e-3 * abs(gold["pair_loss"]), (total, gold["pair_loss"])
+    for b, r in enumerate(res):
+        assert r["parts"] == ["head", "neck", "layer4", "layer3", "layer2", "layer1", "stem"]
+        assert r["collectives"] == 2 * 20 + 4 + 1              # 20 SyncBatchNorm layers forward + backward, 4 buckets, 1 wait
+        for t in range(3):
+            assert abs(r["frame_loss"][t] - gold["pair_frame_loss"][b, t]) <= 1e-3 * abs(gold["pair_frame_loss"][b, t]), (b, t)
+            for s in range(3):
+                assert r["matched"][t][s] == [j for j in gold["pair_matched"][b, t, s].tolist() if j >= 0], (b, t, s)
+        np.testing.assert_allclose(r["bn1_mean"], gold["pair_bn1_running_mean"], atol=1e-4)
+        np.testing.assert_allclose(r["bn1_var"], gold["pair_bn1_running_var"], rtol=1e-4, atol=1e-4)
+        # the reduced arena holds the SUM over the ranks = the gradient of the fixture's summed loss, on BOTH ranks
+        for i, k in enumerate(names):
+            ref, got = float(gold["pair_grad_norm"][i]), r["grad_norm"][i]
+            assert abs(got - ref) <= (5e-2 if k.startswith("detNet.router.") else 5e-3) * ref + 1e-5, (b, k, got, ref)
+    assert res[0]["grad_norm"] == res[1]["grad_norm"]
+
+
+def test_data_parallel_step_as_one_hipgraph_with_rccl_collectives_inside():
+    """The data-parallel step (staged trunk, SyncBatchNorm exchanges with device-resident counts, 4 bucket all-reduces, AdamW)
+    captured as ONE hipGraph with the RCCL collectives inside (one-rank RCCL group, collectives forced on): the replay
+    reproduces the eager step, every replay runs the whole step again (running statistics move, step counter advances)."""
+    _need_gpu()
+    from tests import dp_workers as W
+    (r,) = W.run(W.gpu_whole_step_graph_with_rccl_inside, world=1, backend="nccl", env={"PHNET_FORCE_COLLECTIVES": "1"})
+    assert r["collectives"] == 2 * 20 + 4 + 1, r
+    assert r["replay_loss"][0] == r["replay_loss"][1] and abs(r["replay_loss"][0] - r["loss"]) <= 1e-5 * abs(r["loss"]), r
+    assert r["replay_grad_err"] <= 2e-3 and r["replay_repeat_err"] <= 2e-3, r       # float-atomic ROI scatter: run-to-run noise
+    assert r["running_var_moves"] and r["step_count"] == 3, r                        # 1 eager + 2 replays (capture itself executes nothing)
+
+
+def test_reference_style_syncbn_ddp_wrapping_of_the_hip_model():
+    """trainOL.py:141-146 unchanged around the HIP-backed model: nn.SyncBatchNorm.convert_sync_batchnorm +
+    DistributedDataParallel(find_unused_parameters=True), on a one-rank RCCL group with the collectives forced on
+    (PHNET_FORCE_COLLECTIVES=1: the SyncBatchNorm exchange goes through RCCL) - same loss, gradients and running
+    statistics as the bare model."""
+    _need_gpu()
+    from tests import dp_workers as W
+    (r,) = W.run(W.gpu_ddp_syncbn_wrap, world=1, backend="nccl", env={"PHNET_FORCE_COLLECTIVES": "1"})
+    assert abs(r["loss_ddp"] - r["loss_ref"]) <= 1e-5 * abs(r["loss_ref"]), r
+    assert r["worst_grad_rel"] <= 2e-3 and r["running_var_err"] <= 1e-5, r
+
+
+def test_rccl_collective_inside_a_hipgraph_capture():
+    """An RCCL all-reduce captured in a hipGraph and replayed twice (what GraphedTrainStep(reducer=...) relies on)."""
+    _need_gpu()
+    from tests import dp_workers as W
+    (r,) = W.run(W.gpu_rccl_inside_capture, world=1, backend="nccl")
+    assert r["captured"] and r["value"] == 4.0, r
