@@ -26,6 +26,17 @@ import torch
 import torch.distributed as dist
 
 F32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+BF16_MFMA_PEAK_TFLOPS = 2500.0        # ibid., dense bf16
+# what bounds a GEMM kernel per arithmetic: algorithmic (= f32-product) TFLOP/s it could reach with the matrix pipe always busy
+GEMM_PEAK = {"f32": (F32_MFMA_PEAK_TFLOPS, "f32 (v_mfma_f32_32x32x2_f32)", "dense f32-input MFMA peak"),
+             "bf16x3": (BF16_MFMA_PEAK_TFLOPS / 6, "bf16 (6 x v_mfma_f32_32x32x16_bf16 per 16-deep step of an f32-exact product)",
+                        "dense bf16 MFMA peak 2500 TFLOP/s / 6 MFMAs per product of the exact three-term split"),
+             "split3_bf16": (BF16_MFMA_PEAK_TFLOPS / 6, "bf16 (6 MFMAs per product, split in registers)", "dense bf16 MFMA peak / 6"),
+             "split_bf16": (BF16_MFMA_PEAK_TFLOPS / 3, "bf16 (3 MFMAs per product, two-term split)", "dense bf16 MFMA peak / 3")}
+DTYPE = {"f32": "f32 (f32-input MFMA)",
+         "bf16x3": "f32 storage / accumulation, every product as an EXACT three-term bf16 split (6 bf16 MFMAs, f32-MFMA accuracy)",
+         "split3_bf16": "f32 storage / accumulation, exact three-term bf16 split in registers",
+         "split_bf16": "f32 storage / accumulation, two-term bf16 split (3 MFMAs per product; not parity-grade)"}
 
 
 def parse():
@@ -44,14 +55,20 @@ def parse():
     ap.add_argument("--batched-extra", type=int, default=8,
                     help="N = 1 only: after the headline measurement, also time B clips per GPU and step in a child process and "
                          "report it under the extra key 'batched' (0 = skip)")
-    ap.add_argument("--mma", default="f32", choices=["f32", "split_bf16", "split3_bf16"],
-                    help="arithmetic of the conv / linear GEMM kernels: f32-input MFMA (default, the headline) or split-bf16 "
-                         "(operands split into two bf16 terms, 3 bf16 MFMAs per product, f32 accumulation)")
+    ap.add_argument("--mma", default="bf16x3", choices=["f32", "split_bf16", "split3_bf16", "bf16x3"],
+                    help="arithmetic of the conv / linear GEMM kernels: bf16x3 (default, the headline: f32 operands split EXACTLY "
+                         "into three bf16 terms while a tile is staged into LDS, 6 bf16 MFMAs per product, f32 accumulation - the "
+                         "accuracy of the f32-input MFMA), f32 (v_mfma_f32_32x32x2_f32, the round-1 headline), or the two-term "
+                         "split_bf16 (3 MFMAs per product, ~4x the rounding noise: not parity-grade)")
     ap.add_argument("--split-extra", type=int, default=1,
-                    help="after the headline run, also time the step in split-bf16 arithmetic and report it under the extra key "
-                         "'split_bf16' (0 = skip)")
+                    help="after the headline run, also time the step on the f32-input MFMA (the round-1 arithmetic) and report it "
+                         "under the extra key 'f32_mfma' (0 = skip)")
+    ap.add_argument("--inference-extra", type=int, default=1,
+                    help="N = 1 only: also run the inference workload of BASELINE.json configs[4] (32 clips x 5 frames, lane head + "
+                         "fused decode / NMS, hipGraph) in a child process and report it under the extra key 'inference' (0 = skip)")
+    ap.add_argument("--inference", action="store_true", help="run ONLY the inference workload and print its JSON (used by the child)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-clips", type=int, default=6)
+    ap.add_argument("--cpu-clips", type=int, default=5)
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--eager", action="store_true", help="do not capture the step in a hipGraph (always eager for N>1)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL over xGMI; gloo only for "
@@ -78,6 +95,10 @@ def cpu_baseline(args):
         if v.is_floating_point() and "running" not in k and k.split(".")[-1] not in ("prior_feat_ys", "prior_ys", "priors", "priors_on_featmap"):
             v.requires_grad_(True)
     frames, lanes = synth.make_clip(g, args.frames), synth.make_targets(g, args.frames)
+    O.clip_forward(sd, frames, lanes, g, training=True).backward()        # one untimed warm-up clip (thread pool, allocator, caches)
+    for v in sd.values():
+        if v.requires_grad:
+            v.grad = None
     t0 = time.perf_counter()
     for i in range(args.cpu_clips):
         loss = O.clip_forward(sd, frames, lanes, g, training=True)
@@ -85,7 +106,7 @@ def cpu_baseline(args):
         print(f"[bench] cpu baseline clip {i + 1}/{args.cpu_clips} done at {time.perf_counter() - t0:.1f} s", file=sys.stderr, flush=True)
     dt = time.perf_counter() - t0
     return {"value": args.cpu_clips / dt, "unit": "clips/s", "cores": cores, "kind": "port",
-            "sample": f"{args.cpu_clips} clips of {args.frames}x3x{args.height}x{args.width} fwd+bwd (no optimizer, no warm-up), "
+            "sample": f"{args.cpu_clips} clips of {args.frames}x3x{args.height}x{args.width} fwd+bwd (no optimizer; after one untimed warm-up clip), "
                       f"oracle/phnet_cpu.py on torch CPU fp32, {dt:.1f} s"}
 
 
@@ -93,7 +114,7 @@ def _child_bench(args, flags, what):
     """Runs this script once more in a child process (so that it cannot disturb the run above) and returns its JSON line."""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), *flags, "--no-cpu-baseline", "--no-kernel-timer", "--batched-extra", "0",
-           "--split-extra", "0", "--arch", args.arch, "--frames", str(args.frames), "--height", str(args.height),
+           "--split-extra", "0", "--inference-extra", "0", "--arch", args.arch, "--frames", str(args.frames), "--height", str(args.height),
            "--width", str(args.width)]
     try:
         print(f"[bench] extra: {what} (child process)", file=sys.stderr, flush=True)
@@ -117,27 +138,90 @@ def batched_extra(args):
                     "SyncBatchNorm over B ranks.  A different workload than the headline (1 clip/GPU/step)."}
 
 
-def split_extra(args):
-    """Not the headline: the headline workload (and the batched one) with the GEMM kernels in split-bf16 arithmetic."""
-    out = {"note": "opt-in arithmetic (--mma split_bf16): every conv / linear GEMM splits its f32 operands in registers into two "
-                   "bf16 terms and runs 3 bf16 MFMAs per product with f32 accumulation (csrc/igemm.h) - rounding noise 4-5e-6 of "
-                   "a GEMM's output scale, ~4x the f32-input MFMA's; the model's refinement cascade amplifies that beyond the "
-                   "1e-3 end-to-end parity bound the headline arithmetic meets (tests/test_model_gpu.py), so it is reported "
-                   "here and never as the headline."}
-    d = _child_bench(args, ["--mma", "split_bf16", "--steps", "10", "--warmup", "3"], "split-bf16 arithmetic, 1 clip per GPU and step")
+def f32_extra(args):
+    """Not the headline: the same workload with the GEMM kernels on the f32-input MFMA (round 1's headline arithmetic)."""
+    d = _child_bench(args, ["--mma", "f32", "--steps", "10", "--warmup", "3"], "f32-input MFMA, 1 clip per GPU and step")
     if d is None:
         return None
-    out.update({"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"]})
-    if args.batched_extra > 1:
-        b = _child_bench(args, ["--mma", "split_bf16", "--clips-per-gpu", str(args.batched_extra), "--steps", "6", "--warmup", "2"],
-                         f"split-bf16 arithmetic, {args.batched_extra} clips per GPU and step")
-        if b is not None:
-            out["batched"] = {"clips_per_gpu": args.batched_extra, "value": b["value"], "ms_per_step": b["ms_per_step"]}
-    return out
+    return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
+            "note": "--mma f32: v_mfma_f32_32x32x2_f32 (bit-for-bit an fmaf chain), the headline arithmetic of round 1; same results to "
+                    "rounding (both arithmetics hold the reference goldens at the same tolerances, tests/test_model_gpu.py)"}
+
+
+def inference_extra(args):
+    """Not the headline: BASELINE.json configs[4]."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--inference", "--mma", args.mma, "--arch", args.arch, "--frames", str(args.frames),
+           "--height", str(args.height), "--width", str(args.width)]
+    try:
+        print("[bench] extra: inference, 32 clips x 5 frames (child process)", file=sys.stderr, flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    except Exception as e:                                             # noqa: BLE001
+        print(f"[bench] extra measurement (inference) failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+        return None
+
+
+def run_inference(args):
+    """BASELINE.json configs[4]: 32 clips x T frames, eval: backbone + lane head + fused decode / NMS of every frame, one
+    hipGraph replay per clip, and B clips per replay with the lane head batched across the clips.  The class heads are
+    redrawn so that scores straddle conf_threshold (phnet_amd.synthetic.spread_scores_): every frame feeds ~120 candidates
+    to the NMS and positives to the cross-frame memory (with random-init heads nothing is kept and the decode is empty)."""
+    from phnet_amd import hip_ops
+    from phnet_amd.config import make_cfg
+    from phnet_amd.graphed import GraphedInference
+    from phnet_amd.libs.models.Router4OL import RouterOL
+    from phnet_amd.synthetic import make_clip, spread_scores_
+    hip_ops.set_mma_mode(args.mma)
+    torch.cuda.set_device(0)
+    torch.manual_seed(0)
+    clips, T, H, W = 32, args.frames, args.height, args.width
+    model = RouterOL(make_cfg(img_h=H, img_w=W, arch=args.arch), None).cuda().eval()
+    spread_scores_(model)
+    batch = [make_clip(H, W, T, seed=i).cuda() for i in range(4)]
+    g = GraphedInference(model, batch[0])
+    for i in range(3):
+        g(batch[i % 4])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    kept = []
+    for i in range(clips):
+        rows, nums, anchors = g(batch[i % 4])
+        if i >= clips - 4:
+            kept.append(nums.clone())
+    host = model.lanes_from_device(rows, nums)           # one D2H + Lane objects for the last clip (per-clip host work)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {"workload": f"{clips} clips x {T} frames 3x{H}x{W}, {args.arch}, eval: backbone + lane head + fused decode/NMS per frame, "
+                       "hipGraph; class heads redrawn so that ~half of the 240 anchors pass conf_threshold",
+           "gemm_arithmetic": args.mma, "clips_per_s": round(clips / dt, 2), "frames_per_s": round(clips * T / dt, 1),
+           "ms_per_clip": round(dt / clips * 1e3, 2), "lanes_last_clip": [len(x) for x in host["lane_lines"]],
+           "kept_per_frame_last_4_clips": torch.stack(kept).cpu().tolist()}
+    with torch.no_grad():
+        lines_probe = model.infer_device(batch[0])
+    del lines_probe
+    for B in (8, 32):
+        big = torch.stack([batch[i % 4] for i in range(B)])
+        gb = GraphedInference(model, big)
+        for _ in range(2):
+            gb(big)
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
+        for _ in range(max(1, clips // B) * 2):
+            rb, nb, ab = gb(big)
+        torch.cuda.synchronize()
+        dtb = time.perf_counter() - tb
+        out[f"clips_per_s_batched_{B}"] = round(max(1, clips // B) * 2 * B / dtb, 2)
+        out[f"kept_lanes_batched_{B}"] = int(nb.sum())
+        del gb
+    out["frames_per_s_batched_32"] = round(out["clips_per_s_batched_32"] * T, 1)
+    print(json.dumps(out), flush=True)
 
 
 def main():
     args = parse()
+    if args.inference:
+        return run_inference(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -155,9 +239,7 @@ def main():
     from phnet_amd.libs.utils.loss4OLV3 import Criterion4OL
     from phnet_amd.synthetic import make_clip, make_targets
 
-    if args.mma != "f32":
-        hip_ops.set_mma_mode(args.mma)
-        args.no_kernel_timer = True                  # the per-symbol attribution below knows the f32 kernels only
+    hip_ops.set_mma_mode(args.mma)
     torch.manual_seed(3407)
     cfg = make_cfg(img_h=args.height, img_w=args.width, arch=args.arch)
     model = RouterOL(cfg, Criterion4OL(cfg)).to(dev).train()
@@ -290,30 +372,25 @@ def main():
                     agg[sym][2] = sec_
             total_gemm_s = sum(a[2] for a in agg.values())
             sym, (n, fl, sec) = max(agg.items(), key=lambda kv: kv[1][2])
-            traffic = None
-            try:                                           # PMC passes are separate rocprofv3 runs (profiles/README.md)
-                short = sym.replace(", false", ", false").strip()
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-                if short in pmc:
-                    traffic = pmc[short]["hbm_bytes_per_launch_corrected"]
+            peak, mfma_dtype, peak_note = GEMM_PEAK[args.mma]
+            prof = {}
+            try:                                           # separate rocprofv3 --pmc passes of this bench (profiles/README.md)
+                prof = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")))
             except Exception:                              # noqa: BLE001
-                traffic = None
-            mfma_util = None
-            try:                                           # separate PMC pass on the backbone conv shapes (profiles/README.md)
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_mfma_trunk.json")))
-                vals = [v["mfma_util_pct"] for k, v in pm.items() if ", 16, " in k or "wgrad" in k]
-                mfma_util = {"min": min(vals), "max": max(vals), "source": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE on "
-                             "tests/tools/bench_conv.py --trunk (ResNet-34 stage convs of a 5x320x800 clip), profiles/r01_pmc_mfma_trunk.json"}
-            except Exception:                              # noqa: BLE001
-                mfma_util = None
+                prof = {}
+            traffic = (prof.get("traffic", {}).get(sym) or {}).get("hbm_bytes_per_launch_corrected")
+            mfma_util = prof.get("backbone_conv_mfma_util")
             ach = fl / sec / 1e12
-            roof = {"bound": "mfma", "kernel": sym, "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+            roof = {"bound": "mfma", "kernel": sym, "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                    "frac": round(ach / peak, 4), "traffic": traffic,
+                    "peak_note": f"algorithmic (f32-product) TFLOP/s this arithmetic reaches with the matrix pipe always busy: {peak_note}; "
+                                 "`achieved` counts each f32 multiply-add once, whatever number of MFMAs it costs",
+                    "frac_of_f32_mfma_peak": round(ach / F32_MFMA_PEAK_TFLOPS, 4),
                     "traffic_note": "HBM bytes per launch of this kernel symbol from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                                    "passes of this bench (profiles/r01_pmc_traffic.json; FETCH_SIZE doubled per the gfx950 "
+                                    "passes of this bench (profiles/r02_pmc_summary.json; FETCH_SIZE doubled per the gfx950 "
                                     "correction for 16-B/lane streaming reads)" if traffic else None,
                     "launches": n, "avg_launch_us": round(sec / n * 1e6, 2), "gflop_per_launch": round(fl / n / 1e9, 3),
-                    "mfma_dtype": "f32 (v_mfma_f32_32x32x2_f32)",
+                    "mfma_dtype": mfma_dtype,
                     "all_gemm_kernels": {k: {"launches": v[0], "TFLOP/s": round(v[1] / v[2] / 1e12, 2), "ms_per_step": round(v[2] / steps_timed * 1e3, 3)}
                                          for k, v in sorted(agg.items())},
                     "gemm_ms_per_step": round(total_gemm_s / steps_timed * 1e3, 3), "timing": timer_note,
@@ -327,7 +404,7 @@ def main():
         out = {"metric": f"clips/s ({T}x3x{args.height}x{args.width}) fwd+bwd", "value": round(world * CB * args.steps / dt, 4), "unit": "clips/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "f32" if args.mma == "f32" else "f32 storage and accumulation, bf16x2-split MFMA inputs", "data": "synthetic",
+               "dtype": DTYPE[args.mma], "data": "synthetic",
                "config": {"workload": f"{T}-frame clip 3x{args.height}x{args.width}, {args.arch} + router + lane head, fwd+bwd+AdamW, "
                                       f"{CB} clip{'s' if CB > 1 else ''}/GPU/step, random-init weights", "parallelism": f"dp{world}",
                           "timed_region": "grad-arena memset + forward + loss + backward (+ when N>1: SyncBatchNorm statistic exchanges and "
@@ -338,10 +415,14 @@ def main():
                "loss": round(float(loss.item()) * world, 4), "roofline": roof, "cpu_baseline": cpu}
         if batched is not None:
             out["batched"] = batched
-        if world == 1 and CB == 1 and args.split_extra and use_graph and args.mma == "f32":
-            sp = split_extra(args)
+        if world == 1 and CB == 1 and args.split_extra and use_graph and args.mma != "f32":
+            sp = f32_extra(args)
             if sp is not None:
-                out["split_bf16"] = sp
+                out["f32_mfma"] = sp
+        if world == 1 and CB == 1 and args.inference_extra:
+            inf = inference_extra(args)
+            if inf is not None:
+                out["inference"] = inf
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -17,7 +17,12 @@
 // A Linear layer is the R=S=1 case on an [M,1,1,K] image.
 //
 // Roofline: MFMA-bound (f32-input MFMA, 157.3 TF/s dense).  Algorithmic FLOPs = 2*M*N*K.
+#include <type_traits>
 #include "igemm.h"
+#ifndef PHNET_INTERLEAVE
+#define PHNET_INTERLEAVE 1
+#endif
+static constexpr bool g_interleave = PHNET_INTERLEAVE != 0;
 
 using namespace igemm;
 
@@ -34,11 +39,38 @@ struct ConvShape {
 
 struct RowCoord { int base, iy0, ix0; bool ok; };
 
+// f(integral_constant<0>, t), f(integral_constant<1>, t + 1), ... : a loop body that needs its index at compile time
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void unroll_iterations(F& f, int t) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{}, t + I);
+        unroll_iterations<N, I + 1>(f, t);
+    }
+}
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void tail_iterations(F& f, int t, int end) {
+    if constexpr (I < N) {
+        if (t + I < end) {
+            f(std::integral_constant<int, I>{}, t + I);
+            tail_iterations<N, I + 1>(f, t, end);
+        }
+    }
+}
+
 // The tile program is a device function so that one launch can run tiles of different GEMMs (linear_bwd_fused_kernel);
 // (block, nblocks, split) are what blockIdx.x / gridDim.x / blockIdx.z are for the plain kernel below.
 // AMASK: the A operand is a gradient that still has to pass a ReLU - element (row, k) counts only where amask (the saved
 // forward output of that ReLU, same layout as X) is positive; applied when the tile is written to LDS.
-template <int BM, int BN, bool B_DGRAD, int BKT, bool UNI, bool AMASK = false, int MMA = 0>
+// PF: register prefetch depth in K tiles.  The loads of tile t + PF are issued while tile t is multiplied, so PF tiles of a
+// workgroup are in flight at any time: at one clip the trunk GEMMs are bound by the latency of their operand loads times
+// the little that is in flight per CU (measured: 9 B/clk/CU at PF = 1 against the ~28 B/clk/CU an L2-resident gather
+// sustains, MI355X_MICROARCH.md "Indexed rows"), not by the MFMA pipe - which is why the 2.7x cheaper bf16x3 arithmetic
+// alone changed nothing.  A tile costs 2-4 float4 registers per thread, the LDS double buffer stays.
+// BUF: operand loads through buffer instructions with 32-bit offsets (uniform-tap, undilated, unmasked-A problems only): an
+// out-of-range element is simply given an offset past the end of the tensor and the hardware returns zeros - no 64-bit
+// address arithmetic, no validity select when the tile is written to LDS (the loop is bound by its vector instruction
+// count: 90 per 6 MFMAs before, of which 44 are the split).
+template <int BM, int BN, bool B_DGRAD, int BKT, bool UNI, bool AMASK = false, int MMA = 0, int PF = 1, bool BUF = false>
 __device__ __forceinline__ void igemm_tile(
     const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ bias,
     const float* __restrict__ addend, float* __restrict__ out, const ConvShape& g, int relu,
@@ -55,6 +87,14 @@ __device__ __forceinline__ void igemm_tile(
     constexpr int B_LOADS = B_DGRAD ? (BKT * BN / 4) / THREADS : BN / ROWS_PER_PASS;
     float* As = lds;
     float* Bs = lds + 2 * A_FLOATS;
+    // MMA = 3: bf16 planes instead of f32 images (igemm.h)
+    constexpr bool S3 = MMA == 3;
+    typedef KContigPlanes<BM, BKT> AP3;
+    typedef KContigPlanes<BN, BKT> BP3C;
+    typedef KStridedPlanes<BN, BKT> BP3S;
+    constexpr int B3_BYTES = B_DGRAD ? BP3S::BYTES : BP3C::BYTES;
+    unsigned char* A3 = reinterpret_cast<unsigned char*>(lds);
+    unsigned char* B3 = A3 + 2 * AP3::BYTES;
 
     const int M = g.N * g.Ho * g.Wo;
     const int K = g.R * g.S * g.Ci;
@@ -129,12 +169,60 @@ __device__ __forceinline__ void igemm_tile(
     // LDS (validity bits travel in `mask`: A loads in bits 0.., B loads in bits 16..), so the loop body is straight-line
     // code the compiler can schedule and count (s_waitcnt) exactly.  (A second register set prefetching two tiles ahead
     // was measured too: +4 % on the trunk forward, -3 % on the skinny head GEMMs, no gain on the step - not kept.)
-    f32x4 a_set0[A_LOADS], b_set0[B_LOADS];
-    f32x4 a_relu[AMASK ? A_LOADS : 1];
-    unsigned mask0 = 0;
+    f32x4 a_set[PF][A_LOADS], b_set[PF][B_LOADS];
+    f32x4 r_set[PF][AMASK ? A_LOADS : 1];
+    unsigned mask_set[PF];
     // loads the K tile that starts at kt; MUST be called with kt = k_begin, k_begin+BKT, ... in order
-    auto load_global = [&](int kt, f32x4 (&a_reg)[A_LOADS], f32x4 (&b_reg)[B_LOADS], unsigned& mask) {
+    // ---- BUF: per-thread byte offsets fixed over the K loop + one scalar offset per tile ----
+    constexpr unsigned OOB = 0x80000000u;                 // past the end of every tensor of this path (< 2 GB each)
+    int a_off[BUF ? A_LOADS : 1], b_off[BUF ? B_LOADS : 1];
+    __amdgpu_buffer_rsrc_t x_rsrc, w_rsrc;
+    if constexpr (BUF) {
+        static_assert(UNI && !AMASK, "buffer-load path: uniform tap, no ReLU mask");
+        x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)min((long)g.N * g.Hi * g.Wi * g.Ci * 4, (long)0x7fffffff), 0x00020000);
+        w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, (int)min((long)g.Co * K * 4, (long)0x7fffffff), 0x00020000);
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) {
+            a_off[i] = ((rc[i].base + rc[i].iy0 * g.Wi + rc[i].ix0) * g.Ci + a_chunk * 4) * 4;
+            if (!rc[i].ok) rc[i].iy0 = -(1 << 28);                       // fails the row test below for every tap
+        }
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i) {
+            if (!B_DGRAD) {
+                const int n = n0 + a_row + ROWS_PER_PASS * i;
+                b_off[i] = n < g.Co ? (n * K + a_chunk * 4) * 4 : (int)OOB;
+            } else {
+                const int n = n0 + b_ch[i] * 4;
+                b_off[i] = n < g.Co ? (b_kk[i] * g.R * g.S * g.Co + n) * 4 : (int)OOB;
+            }
+        }
+    }
+    auto load_global = [&](int kt, f32x4 (&a_reg)[A_LOADS], f32x4 (&b_reg)[B_LOADS], f32x4 (&a_relu)[AMASK ? A_LOADS : 1], unsigned& mask) {
         mask = 0;
+        if constexpr (BUF) {
+            const bool tile_ok = kt < k_end;                             // uniform: K and the split bounds are multiples of BKT
+            const int s_tap = ((ur * g.Wi + uq) * g.Ci + uc0) * 4;
+#pragma unroll
+            for (int i = 0; i < A_LOADS; ++i) {
+                const bool ok = tile_ok && (unsigned)(rc[i].iy0 + ur) < (unsigned)g.Hi && (unsigned)(rc[i].ix0 + uq) < (unsigned)g.Wi;
+                a_reg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, ok ? a_off[i] + s_tap : (int)OOB, 0, 0));
+            }
+            // B: scalar part of the offset
+            int s_b;
+            if (!B_DGRAD) s_b = kt * 4;
+            else s_b = ((uc0 * g.R + (g.R - 1 - ur)) * g.S + (g.S - 1 - uq)) * g.Co * 4;
+#pragma unroll
+            for (int i = 0; i < B_LOADS; ++i)            // (an invalid column already sits at OOB; adding the small s_b keeps it there)
+                b_reg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, tile_ok ? b_off[i] + s_b : (int)OOB, 0, 0));
+            uc0 += BKT;
+            const int wc = uc0 >= g.Ci;
+            uc0 = wc ? 0 : uc0;
+            uq += wc;
+            const int wq = uq == g.S;
+            uq = wq ? 0 : uq;
+            ur += wq;
+            return;
+        }
         // A: CHUNKS consecutive lanes fetch BKT*4 contiguous bytes of one pixel tap
         const int k0 = kt + a_chunk * 4;
         const bool kok = k0 < k_end;
@@ -177,36 +265,47 @@ __device__ __forceinline__ void igemm_tile(
                 if (!uni) kpos_advance(kb[i], g.Ci);
             }
         }
-        if (uni) {                                       // scalar tap walk
+        if (uni) {                                       // scalar tap walk, branch-free (a branch here costs a vmcnt(0))
             uc0 += BKT;
-            if (uc0 >= g.Ci) {
-                uc0 = 0;
-                if (++uq == g.S) { uq = 0; ++ur; }
-            }
+            const int wc = uc0 >= g.Ci;
+            uc0 = wc ? 0 : uc0;
+            uq += wc;
+            const int wq = uq == g.S;
+            uq = wq ? 0 : uq;
+            ur += wq;
         }
     };
-    auto store_lds = [&](int buf, const f32x4 (&a_reg)[A_LOADS], const f32x4 (&b_reg)[B_LOADS], unsigned mask) {
+    auto store_lds = [&](int buf, const f32x4 (&a_reg)[A_LOADS], const f32x4 (&b_reg)[B_LOADS], const f32x4 (&a_relu)[AMASK ? A_LOADS : 1],
+                         unsigned mask) {
         float* a = As + buf * A_FLOATS;
         float* b = Bs + buf * B_FLOATS;
+        unsigned char* a3 = A3 + buf * AP3::BYTES;
+        unsigned char* b3 = B3 + buf * B3_BYTES;
         const f32x4 zero{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i) {
-            f32x4 v = (mask >> i) & 1u ? a_reg[i] : zero;
+            f32x4 v = BUF ? a_reg[i] : ((mask >> i) & 1u ? a_reg[i] : zero);
             if (AMASK) {
                 v.x = a_relu[i].x > 0.f ? v.x : 0.f; v.y = a_relu[i].y > 0.f ? v.y : 0.f;
                 v.z = a_relu[i].z > 0.f ? v.z : 0.f; v.w = a_relu[i].w > 0.f ? v.w : 0.f;
             }
-            *reinterpret_cast<f32x4*>(a + (a_row + ROWS_PER_PASS * i) * A_PITCH + a_chunk * 4) = v;
+            if (S3) store_split3<AP3::PLANE>(a3, (a_row + ROWS_PER_PASS * i) * AP3::PITCH + a_chunk * 8, v);
+            else *reinterpret_cast<f32x4*>(a + (a_row + ROWS_PER_PASS * i) * A_PITCH + a_chunk * 4) = v;
         }
         if (!B_DGRAD) {
 #pragma unroll
-            for (int i = 0; i < B_LOADS; ++i)
-                *reinterpret_cast<f32x4*>(b + (a_row + ROWS_PER_PASS * i) * B_PITCH + a_chunk * 4) =
-                    (mask >> (16 + i)) & 1u ? b_reg[i] : zero;
+            for (int i = 0; i < B_LOADS; ++i) {
+                const f32x4 v = BUF ? b_reg[i] : ((mask >> (16 + i)) & 1u ? b_reg[i] : zero);
+                if (S3) store_split3<BP3C::PLANE>(b3, (a_row + ROWS_PER_PASS * i) * BP3C::PITCH + a_chunk * 8, v);
+                else *reinterpret_cast<f32x4*>(b + (a_row + ROWS_PER_PASS * i) * B_PITCH + a_chunk * 4) = v;
+            }
         } else {
 #pragma unroll
-            for (int i = 0; i < B_LOADS; ++i)
-                *reinterpret_cast<f32x4*>(b + b_kk[i] * B_PITCH + b_ch[i] * 4) = (mask >> (16 + i)) & 1u ? b_reg[i] : zero;
+            for (int i = 0; i < B_LOADS; ++i) {
+                const f32x4 v = BUF ? b_reg[i] : ((mask >> (16 + i)) & 1u ? b_reg[i] : zero);
+                if (S3) store_split3<BP3S::PLANE>(b3, b_kk[i] * BP3S::PITCH + b_ch[i] * 8, v);
+                else *reinterpret_cast<f32x4*>(b + b_kk[i] * B_PITCH + b_ch[i] * 4) = v;
+            }
         }
     };
 
@@ -230,6 +329,18 @@ __device__ __forceinline__ void igemm_tile(
     }
 
     auto multiply_tile = [&](int buf, int kt) {
+        if (S3) {
+            // no early exit on a ragged K tail here: ds_read_b64_tr_b16 needs every lane (the tail of the tile is zeros)
+#pragma unroll
+            for (int ks = 0; ks < BKT / BK; ++ks) {
+                Frag3 a[FM], b[FN];
+                read_kcontig3<FM, AP3::PITCH, AP3::PLANE>(A3 + buf * AP3::BYTES + wm * AP3::PITCH, lane, ks, a);
+                if (!B_DGRAD) read_kcontig3<FN, BP3C::PITCH, BP3C::PLANE>(B3 + buf * B3_BYTES + wn * BP3C::PITCH, lane, ks, b);
+                else read_kstrided3<FN, BP3S::PITCH, BP3S::PLANE>(B3 + buf * B3_BYTES + wn * 2, lane, ks, b);
+                mma3_step<FM, FN>(a, b, acc);
+            }
+            return;
+        }
 #pragma unroll
         for (int ks = 0; ks < BKT / BK; ++ks) {
             if (BKT > BK && kt + ks * BK >= k_end) break;              // ragged K tail of a deep tile
@@ -237,27 +348,49 @@ __device__ __forceinline__ void igemm_tile(
             read_kcontig<FM, A_PITCH>(As + buf * A_FLOATS + wm * A_PITCH, lane, ks, a);
             if (!B_DGRAD) read_kcontig<FN, B_PITCH>(Bs + buf * B_FLOATS + wn * B_PITCH, lane, ks, b);
             else read_kstrided<FN, B_PITCH>(Bs + buf * B_FLOATS + wn, lane, ks, b);
-            mma_any<MMA, FM, FN>(a, b, acc);
+            mma_any<S3 ? 0 : MMA, FM, FN>(a, b, acc);
         }
     };
 
     if (k_begin < k_end) {
         const int ntiles = (k_end - k_begin + BKT - 1) / BKT;
-        load_global(k_begin, a_set0, b_set0, mask0);
-        store_lds(0, a_set0, b_set0, mask0);
+        // ring of PF register sets: slot (t mod PF) holds tile t until it has been written to LDS (one iteration before it is
+        // multiplied), then takes tile t + PF.  Loads past the end are fully masked (they read element 0).
+#pragma unroll
+        for (int d = 0; d < PF; ++d) load_global(k_begin + d * BKT, a_set[d], b_set[d], r_set[d], mask_set[d]);
+        store_lds(0, a_set[0], b_set[0], r_set[0], mask_set[0]);
         __syncthreads();
         int buf = 0;
-        for (int t = 0; t < ntiles; ++t) {
-            load_global(k_begin + (t + 1) * BKT, a_set0, b_set0, mask0);      // past the end: fully masked
-            multiply_tile(buf, k_begin + t * BKT);
+        // one iteration: slot U was emptied an iteration ago and takes tile tt + PF; tile tt (in LDS) is multiplied; tile
+        // tt + 1 moves from its slot to the other LDS buffer.  Straight-line code (no branch between the loads and their use:
+        // hipcc answers a branch with s_waitcnt vmcnt(0), which would drain the whole ring every iteration).
+        auto iteration = [&](auto U, int tt) {
+            constexpr int u = decltype(U)::value;
+            load_global(k_begin + (tt + PF) * BKT, a_set[u], b_set[u], r_set[u], mask_set[u]);
+            multiply_tile(buf, k_begin + tt * BKT);
             // keep the LDS fill (and the wait for the global loads in front of it) BEHIND the MFMAs: left alone, the
             // scheduler hoists it above them - the operands are already in registers - and every wave then sits out its
             // full load latency before it issues a single MFMA
-            __builtin_amdgcn_sched_barrier(0);
-            store_lds(buf ^ 1, a_set0, b_set0, mask0);
+            // (with a deep ring the loads are long since complete: the scheduler is free to interleave the split / LDS fill of
+            // the next tile with this tile's MFMAs, which would otherwise leave the vector ALU idle while the matrix pipe drains)
+            if (PF == 1) __builtin_amdgcn_sched_barrier(0);
+            constexpr int v = (u + 1) % PF;
+            store_lds(buf ^ 1, a_set[v], b_set[v], r_set[v], mask_set[v]);
+            if (PF > 1 && S3 && g_interleave) {
+                // one MFMA, then a handful of the next tile's split / address instructions, ...: the matrix pipe takes an MFMA
+                // every 32 cycles and blocks the vector issue for 8 of them
+#pragma unroll
+                for (int i = 0; i < 6 * FM * FN * (BKT / BK); ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, (14 + FM * FN - 1) / (FM * FN), 0);
+                }
+            }
             __syncthreads();
             buf ^= 1;
-        }
+        };
+        int t = 0;
+        for (; t + PF <= ntiles; t += PF) unroll_iterations<PF>(iteration, t);
+        if (PF > 1) tail_iterations<PF - 1>(iteration, t, ntiles);
     }
 
     // ---- epilogue: bias / relu, or raw partial sums when split-K --------------------------------
@@ -276,13 +409,13 @@ __device__ __forceinline__ void igemm_tile(
     }
 }
 
-template <int BM, int BN, bool B_DGRAD, int BKT, bool UNI, int MMA = 0>
+template <int BM, int BN, bool B_DGRAD, int BKT, bool UNI, int MMA = 0, int PF = 1, bool BUF = false>
 __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(
     const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ bias,
     const float* __restrict__ addend, float* __restrict__ out, ConvShape g, int relu)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    igemm_tile<BM, BN, B_DGRAD, BKT, UNI, false, MMA>(X, W, bias, addend, out, g, relu, lds, blockIdx.x, gridDim.x, blockIdx.z);
+    igemm_tile<BM, BN, B_DGRAD, BKT, UNI, false, MMA, PF, BUF>(X, W, bias, addend, out, g, relu, lds, blockIdx.x, gridDim.x, blockIdx.z);
 }
 
 // out[i] = sum_z part[z][i] (+bias[i % ncols]) (relu)
@@ -325,18 +458,26 @@ struct WgradShape {
 
 // out: dW itself when g.splits == 1 (written or accumulated in the epilogue) else the split-K partial buffer
 // [splits][Co*NC + Co] (the trailing Co floats of every split hold its bias-gradient partial).
-template <int BM, int BN, int MMA = 0>
+template <int BM, int BN, int MMA = 0, int BKW = BK>
 __global__ __launch_bounds__(THREADS) void conv_wgrad_kernel(
     const float* __restrict__ dY, const float* __restrict__ X, float* __restrict__ out, float* __restrict__ dbias,
     WgradShape g, int want_bias, int accumulate)
 {
     constexpr int TM = BM / 2, TN = BN / 2, FM = TM / 32, FN = TN / 32;
-    constexpr int A_PITCH = KStridedTile<BM, BK>::PITCH, B_PITCH = KStridedTile<BN, BK>::PITCH;
-    constexpr int A_FLOATS = KStridedTile<BM, BK>::FLOATS, B_FLOATS = KStridedTile<BN, BK>::FLOATS;
-    constexpr int A_LOADS = BM / 64, B_LOADS = BN / 64;      // BK*BM/4 float4 over 256 threads
-    __shared__ __attribute__((aligned(16))) float lds[2 * (A_FLOATS + B_FLOATS)];
+    // BKW = pixels per K step (16; 32 for the staged-split arithmetic, whose MFMA burst per step is 2.7x shorter)
+    constexpr int A_PITCH = KStridedTile<BM, BKW>::PITCH, B_PITCH = KStridedTile<BN, BKW>::PITCH;
+    constexpr int A_FLOATS = KStridedTile<BM, BKW>::FLOATS, B_FLOATS = KStridedTile<BN, BKW>::FLOATS;
+    constexpr int A_LOADS = BKW * BM / 4 / THREADS, B_LOADS = BKW * BN / 4 / THREADS;      // float4 loads per thread and K step
+    constexpr bool S3 = MMA == 3;                            // bf16 planes (igemm.h), both operands K-strided: transposed reads
+    typedef KStridedPlanes<BM, BKW> AP3;
+    typedef KStridedPlanes<BN, BKW> BP3;
+    constexpr int LDS_BYTES = S3 ? 2 * (AP3::BYTES + BP3::BYTES) : 2 * (A_FLOATS + B_FLOATS) * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
+    float* lds = reinterpret_cast<float*>(lds_raw);
     float* As = lds;
     float* Bs = lds + 2 * A_FLOATS;
+    unsigned char* A3 = lds_raw;
+    unsigned char* B3 = lds_raw + 2 * AP3::BYTES;
 
     const int NC = g.R * g.S * g.Ci;                         // GEMM N
     const int P = g.N * g.Ho * g.Wo;                         // GEMM K (pixels)
@@ -393,7 +534,7 @@ __global__ __launch_bounds__(THREADS) void conv_wgrad_kernel(
         if (advance) {                                   // pixel carry of the B gather: BEFORE the loads, so that nothing but
 #pragma unroll                                           // straight-line code sits between them and the MFMAs
             for (int i = 0; i < B_LOADS; ++i) {
-                b_ox[i] += BK;
+                b_ox[i] += BKW;
                 while (b_ox[i] >= g.Wo) {
                     b_ox[i] -= g.Wo;
                     if (++b_oy[i] == g.Ho) { b_oy[i] = 0; ++b_n[i]; }
@@ -423,11 +564,15 @@ __global__ __launch_bounds__(THREADS) void conv_wgrad_kernel(
         for (int i = 0; i < A_LOADS; ++i) {
             const f32x4 v = (lmask >> i) & 1u ? a_reg[i] : zero;
             if (bias_block) bsum[i] += v;
-            *reinterpret_cast<f32x4*>(As + buf * A_FLOATS + a_kk[i] * A_PITCH + a_ch[i]) = v;
+            if (S3) store_split3<AP3::PLANE>(A3 + buf * AP3::BYTES, a_kk[i] * AP3::PITCH + a_ch[i] * 2, v);
+            else *reinterpret_cast<f32x4*>(As + buf * A_FLOATS + a_kk[i] * A_PITCH + a_ch[i]) = v;
         }
 #pragma unroll
-        for (int i = 0; i < B_LOADS; ++i)
-            *reinterpret_cast<f32x4*>(Bs + buf * B_FLOATS + b_kk[i] * B_PITCH + b_col[i]) = (lmask >> (16 + i)) & 1u ? b_reg[i] : zero;
+        for (int i = 0; i < B_LOADS; ++i) {
+            const f32x4 v = (lmask >> (16 + i)) & 1u ? b_reg[i] : zero;
+            if (S3) store_split3<BP3::PLANE>(B3 + buf * BP3::BYTES, b_kk[i] * BP3::PITCH + b_col[i] * 2, v);
+            else *reinterpret_cast<f32x4*>(Bs + buf * B_FLOATS + b_kk[i] * B_PITCH + b_col[i]) = v;
+        }
     };
 
     // unsplit + accumulate: start the accumulators from the old gradient (its HBM latency overlaps the first tile's loads;
@@ -451,12 +596,22 @@ __global__ __launch_bounds__(THREADS) void conv_wgrad_kernel(
         store_lds(0);
         __syncthreads();
         int buf = 0;
-        for (int pt = p_begin; pt < p_end; pt += BK) {
-            load_global(pt + BK, true);                  // past the end: fully masked
-            float a[FM][8], b[FN][8];
-            read_kstrided<FM, A_PITCH>(As + buf * A_FLOATS + wm, lane, 0, a);
-            read_kstrided<FN, B_PITCH>(Bs + buf * B_FLOATS + wn, lane, 0, b);
-            mma_any<MMA, FM, FN>(a, b, acc);
+        for (int pt = p_begin; pt < p_end; pt += BKW) {
+            load_global(pt + BKW, true);                 // past the end: fully masked
+#pragma unroll
+            for (int ks = 0; ks < BKW / BK; ++ks) {
+                if (S3) {
+                    Frag3 a[FM], b[FN];
+                    read_kstrided3<FM, AP3::PITCH, AP3::PLANE>(A3 + buf * AP3::BYTES + wm * 2, lane, ks, a);
+                    read_kstrided3<FN, BP3::PITCH, BP3::PLANE>(B3 + buf * BP3::BYTES + wn * 2, lane, ks, b);
+                    mma3_step<FM, FN>(a, b, acc);
+                } else {
+                    float a[FM][8], b[FN][8];
+                    read_kstrided<FM, A_PITCH>(As + buf * A_FLOATS + wm, lane, ks, a);
+                    read_kstrided<FN, B_PITCH>(Bs + buf * B_FLOATS + wn, lane, ks, b);
+                    mma_any<S3 ? 0 : MMA, FM, FN>(a, b, acc);
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);           // the LDS fill (and its wait for the loads) stays behind the MFMAs
             store_lds(buf ^ 1);
             __syncthreads();
@@ -490,7 +645,7 @@ __global__ __launch_bounds__(THREADS) void conv_wgrad_kernel(
         if (tid < BM && m0 + tid < g.Co) {
             float t = 0.f;
 #pragma unroll
-            for (int k = 0; k < BK; ++k) t += As[k * A_PITCH + tid];
+            for (int k = 0; k < BKW; ++k) t += As[k * A_PITCH + tid];
             if (direct) dbias[m0 + tid] = accumulate ? dbias[m0 + tid] + t : t;
             else dst[(size_t)g.Co * NC + m0 + tid] = t;
         }
@@ -694,13 +849,17 @@ __global__ void pad_channels_kernel(const float* __restrict__ src, float* __rest
 
 struct TileChoice { int bm, bn; };
 
-int g_mma_mode = 0;                                          // 0: f32-input MFMA (product default); 1: split-bf16 MFMA (phnet_tune_mma)
+int g_mma_mode = 3;                                          // 3 (default): exact 3-term bf16 split at staging; 0: f32-input MFMA; 1 / 2: bf16 splits in registers (phnet_tune_mma)
+int g_buf_loads = 1;                                         // buffer-load operand path where it applies (tuning: phnet_tune_force_k_tile(-200 / -201))
+int g_pf = 4;                                                // register prefetch depth in K tiles (tuning: phnet_tune_force_k_tile(-101 / -102 / -104))
+int g_deep_kt3 = 64;                                         // K tile of the few-rows GEMMs in mode 3 (tuning: phnet_tune_force_k_tile(-32 / -64))
 
 TileChoice pick_tile(long M, long N)
 {
     // Measured on MI355X (tests/tools/bench_conv.py): the problems of this path are small (a 5-frame clip), so what
     // matters is the number of co-resident workgroups per CU, not the tile's arithmetic intensity: 64x64 tiles with
     // the block count topped up to ~1250 by split-K beat the larger tiles on every trunk layer (72-80 us vs 85-130 us).
+    if (g_mma_mode == 3 && M <= 2048) return {64, 64};          // few-rows GEMMs run K tile 64: 110 KB of LDS with 64x64 tiles
     if (g_mma_mode >= 1) {
         // split-bf16: the loop is bound by the operand split (VALU) and the LDS reads per MFMA, both of which shrink with
         // the wave tile - problems with enough tiles take the larger ones (bench_conv.py --mma --clips 8: 128x128 is
@@ -717,7 +876,8 @@ struct ConvPlan { int bm, bn, splits; long tiles; };
 // (the MFMA work per barrier is 5x shorter there; measured 44-54 us vs 51-58 us on the trunk layers)
 int k_tile_for(long M, int K, int ci, int bm, int bn)
 {
-    if (M <= 2048 && K >= 64) return 64;
+    if (M <= 2048 && K >= 64) return (g_mma_mode == 3 && g_deep_kt3 == 32) ? 32 : 64;
+    if (g_mma_mode == 3) return BK;                                   // 37 KB of LDS per 64x64 workgroup: four per CU
     if (g_mma_mode >= 1 && bm == 64 && bn == 64 && ci % 32 == 0) return 32;
     return BK;
 }
@@ -726,6 +886,7 @@ int g_force_bm = 0, g_force_bn = 0, g_force_splits = 0;      // tuning aid (phne
 int g_force_kt = 0;                                          // tuning aid (phnet_tune_force_k_tile)
 int g_uniform_tap = 1;                                       // tuning aid (phnet_tune_force_k_tile(-1) switches the uniform-tap variant off)
 int g_wgrad_bm128 = 1, g_wgrad_target = 768;                // tuning aids (phnet_tune_wgrad)
+int g_wgrad_bkw = 16;                                        // tuning aid: pixels per K step of the staged-split wgrad kernel (phnet_tune_wgrad bit 2 of arg 0 -> 32)
 int g_wgrad_smallp = 1;                                      // bit 1 of phnet_tune_wgrad's first argument switches the few-rows kernel off
 int g_smallp_max_tiles = 400;                                 // measured: 64 -> 400 tiles saves 0.75 ms per step, 1300 nothing more
 
@@ -770,23 +931,36 @@ int launch_conv(const float* X, const float* W, const float* bias, const float* 
     const int bkt = g_force_kt ? g_force_kt : k_tile_for(M, K, g.Ci, t.bm, t.bn);
     const int ksteps = (K + bkt - 1) / bkt;
     g.k_per_split = ((ksteps + splits - 1) / splits) * bkt;
-#define PHNET_LAUNCH_CONV__(BM_, BN_, BKT_, UNI_, MMA_)                                                                 \
+#define PHNET_LAUNCH_CONV___(BM_, BN_, BKT_, UNI_, MMA_, PF_)                                                           \
     do {                                                                                                                \
-        constexpr size_t lds_ = 2 * (KContigTile<BM_, BKT_>::FLOATS +                                                   \
-                                     (DGRAD ? KStridedTile<BN_, BKT_>::FLOATS : KContigTile<BN_, BKT_>::FLOATS)) * 4;   \
+        if (UNI_ && g.in_dil == 1 && g_buf_loads && MMA_ == 3) PHNET_LAUNCH_CONV____(BM_, BN_, BKT_, UNI_, MMA_, PF_, UNI_); \
+        else PHNET_LAUNCH_CONV____(BM_, BN_, BKT_, UNI_, MMA_, PF_, false);                                             \
+    } while (0)
+#define PHNET_LAUNCH_CONV____(BM_, BN_, BKT_, UNI_, MMA_, PF_, BUF_)                                                    \
+    do {                                                                                                                \
+        constexpr size_t lds_ = MMA_ == 3                                                                               \
+            ? 2 * (size_t)(KContigPlanes<BM_, BKT_>::BYTES +                                                            \
+                           (DGRAD ? KStridedPlanes<BN_, BKT_>::BYTES : KContigPlanes<BN_, BKT_>::BYTES))                \
+            : 2 * (size_t)(KContigTile<BM_, BKT_>::FLOATS +                                                             \
+                           (DGRAD ? KStridedTile<BN_, BKT_>::FLOATS : KContigTile<BN_, BKT_>::FLOATS)) * 4;             \
         static bool attr_set_ = false;                                                                                  \
         if (lds_ > 64 * 1024 && !attr_set_) {                                                                           \
-            (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BM_, BN_, DGRAD, BKT_, UNI_, MMA_>,                \
+            (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BM_, BN_, DGRAD, BKT_, UNI_, MMA_, PF_, BUF_>,     \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_);                                 \
             attr_set_ = true;                                                                                           \
         }                                                                                                               \
-        hipLaunchKernelGGL((conv_igemm_kernel<BM_, BN_, DGRAD, BKT_, UNI_, MMA_>), grid, dim3(THREADS), lds_, st, X, W, \
-                           bias, addend, dst, g, relu);                                                                 \
+        hipLaunchKernelGGL((conv_igemm_kernel<BM_, BN_, DGRAD, BKT_, UNI_, MMA_, PF_, BUF_>), grid, dim3(THREADS), lds_, st, \
+                           X, W, bias, addend, dst, g, relu);                                                           \
     } while (0)
+#define PHNET_LAUNCH_CONV__(BM_, BN_, BKT_, UNI_, MMA_) PHNET_LAUNCH_CONV___(BM_, BN_, BKT_, UNI_, MMA_, 1)
 #define PHNET_LAUNCH_CONV_(BM_, BN_, BKT_, UNI_)                                                                        \
     do {                                                                                                                \
         if (g_mma_mode == 1) PHNET_LAUNCH_CONV__(BM_, BN_, BKT_, UNI_, 1);                                              \
         else if (g_mma_mode == 2) PHNET_LAUNCH_CONV__(BM_, BN_, BKT_, UNI_, 2);                                         \
+        else if (g_mma_mode == 3 && g_pf == 4) PHNET_LAUNCH_CONV___(BM_, BN_, BKT_, UNI_, 3, 4);                        \
+        else if (g_mma_mode == 3 && g_pf == 2) PHNET_LAUNCH_CONV___(BM_, BN_, BKT_, UNI_, 3, 2);                        \
+        else if (g_mma_mode == 3) PHNET_LAUNCH_CONV___(BM_, BN_, BKT_, UNI_, 3, 1);                                     \
+        else if (g_pf == 4) PHNET_LAUNCH_CONV___(BM_, BN_, BKT_, UNI_, 0, 4);                                           \
         else PHNET_LAUNCH_CONV__(BM_, BN_, BKT_, UNI_, 0);                                                              \
     } while (0)
 #define PHNET_LAUNCH_CONV(BM_, BN_, UNI_)                                                                               \
@@ -802,6 +976,8 @@ int launch_conv(const float* X, const float* W, const float* bias, const float* 
     else if (t.bm == 64 && t.bn == 128) PHNET_LAUNCH_CONV(64, 128, false);
     else if (uni) PHNET_LAUNCH_CONV(64, 64, true);
     else PHNET_LAUNCH_CONV(64, 64, false);
+#undef PHNET_LAUNCH_CONV____
+#undef PHNET_LAUNCH_CONV___
 #undef PHNET_LAUNCH_CONV__
 #undef PHNET_LAUNCH_CONV_
 #undef PHNET_LAUNCH_CONV
@@ -839,21 +1015,26 @@ PHNET_API int phnet_tune_force_conv_tile(int32_t bm, int32_t bn, int32_t splits)
 PHNET_API int phnet_tune_wgrad(int32_t allow_bm128, int32_t target_blocks)
 {
     if (target_blocks < 1) return PHNET_ERR_ARG;
-    g_wgrad_bm128 = allow_bm128 & 1; g_wgrad_smallp = !(allow_bm128 & 2); g_wgrad_target = target_blocks;
+    g_wgrad_bm128 = allow_bm128 & 1; g_wgrad_smallp = !(allow_bm128 & 2); g_wgrad_bkw = (allow_bm128 & 4) ? 32 : 16;
+    g_wgrad_target = target_blocks;
     return PHNET_OK;
 }
 
 // Tuning aid (process-global): arithmetic of the GEMM kernels.  0 = f32-input MFMA (default), 1 = split-bf16 (igemm.h).
 PHNET_API int phnet_tune_mma(int32_t mode)
 {
-    if (mode < 0 || mode > 2) return PHNET_ERR_ARG;
+    if (mode < 0 || mode > 3) return PHNET_ERR_ARG;
     g_mma_mode = mode;
+    g_pf = mode == 3 ? 4 : 1;                                  // the staged-split loop runs with a 4-tile register ring
     return PHNET_OK;
 }
 
 PHNET_API int phnet_tune_force_k_tile(int32_t kt)
 {
     if (kt == -1 || kt == -2) { g_uniform_tap = kt == -2; return PHNET_OK; }     // -1: uniform-tap variant off, -2: on again
+    if (kt == -32 || kt == -64) { g_deep_kt3 = -kt; return PHNET_OK; }
+    if (kt == -101 || kt == -102 || kt == -104) { g_pf = -kt - 100; return PHNET_OK; }
+    if (kt == -200 || kt == -201) { g_buf_loads = -kt - 200; return PHNET_OK; }
     if (kt != 0 && kt != 16 && kt != 32 && kt != 64) return PHNET_ERR_ARG;
     g_force_kt = kt;
     return PHNET_OK;
@@ -976,13 +1157,22 @@ PHNET_API int phnet_conv2d_wgrad(const float* dy, const float* x, float* dw, flo
     const long tiles = ceil_div64(Co, bm) * ceil_div64(NC, bn);
     const long row = (long)Co * NC + Co;
     while (splits > 1 && (!workspace || (uint64_t)(splits * row * sizeof(float)) > ws_bytes)) --splits;
-    const long psteps = ceil_div64(max(P, (long)1), BK);
+    const int bkw = (g_mma_mode == 3 && g_wgrad_bkw == 32) ? 32 : BK;      // pixels per K step of the kernel picked below
+    const long psteps = ceil_div64(max(P, (long)1), bkw);
     g.splits = (int)splits;
-    g.pix_per_split = (int)(ceil_div64(psteps, splits) * BK);
+    g.pix_per_split = (int)(ceil_div64(psteps, splits) * bkw);
     float* out = splits > 1 ? (float*)workspace : dw;
     dim3 grid((unsigned)tiles, 1, (unsigned)splits);
     const int want_bias = dbias != nullptr;
-    if (bm == 128 && g_mma_mode == 2)
+    if (g_mma_mode == 3 && bkw == 32 && bm == 128)
+        hipLaunchKernelGGL((conv_wgrad_kernel<128, 64, 3, 32>), grid, dim3(THREADS), 0, st, dy, x, out, dbias, g, want_bias, accumulate);
+    else if (g_mma_mode == 3 && bkw == 32)
+        hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 3, 32>), grid, dim3(THREADS), 0, st, dy, x, out, dbias, g, want_bias, accumulate);
+    else if (g_mma_mode == 3 && bm == 128)
+        hipLaunchKernelGGL((conv_wgrad_kernel<128, 64, 3>), grid, dim3(THREADS), 0, st, dy, x, out, dbias, g, want_bias, accumulate);
+    else if (g_mma_mode == 3)
+        hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 3>), grid, dim3(THREADS), 0, st, dy, x, out, dbias, g, want_bias, accumulate);
+    else if (bm == 128 && g_mma_mode == 2)
         hipLaunchKernelGGL((conv_wgrad_kernel<128, 64, 2>), grid, dim3(THREADS), 0, st, dy, x, out, dbias, g, want_bias, accumulate);
     else if (g_mma_mode == 2)
         hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 2>), grid, dim3(THREADS), 0, st, dy, x, out, dbias, g, want_bias, accumulate);

@@ -16,17 +16,19 @@ _WS = {}
 TIMER = None
 
 
-_MMA_MODE = 0        # last template argument of the GEMM kernels (set_mma_mode); only used to NAME kernel symbols for bench.py
+_MMA_MODE = 3        # arithmetic of the GEMM kernels (set_mma_mode; 3 = "bf16x3", the library default); here only used to NAME kernel symbols for bench.py
 
 
-def _gemm_symbol(m, co, k, ws_bytes, dgrad, ci_a):
+def _gemm_symbol(m, co, k, ws_bytes, dgrad, ci_a, in_dil=1):
     import ctypes
     bm, bn, sp, kt = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
     check(lib().phnet_conv2d_plan(m, co, k, ws_bytes, ctypes.byref(bm), ctypes.byref(bn), ctypes.byref(sp), ctypes.byref(kt)),
           "phnet_conv2d_plan")
     uni = bm.value == 64 and bn.value == 64 and ci_a % kt.value == 0      # uniform-tap variant (csrc/conv.hip)
+    pf = 4 if _MMA_MODE == 3 else 1                                       # register prefetch ring; buffer loads (launch_conv)
+    buf = uni and _MMA_MODE == 3 and in_dil == 1
     return (f"conv_igemm_kernel<{bm.value}, {bn.value}, {'true' if dgrad else 'false'}, {kt.value}, {'true' if uni else 'false'}, "
-            f"{_MMA_MODE}>", sp.value)
+            f"{_MMA_MODE}, {pf}, {'true' if buf else 'false'}>", sp.value)
 
 
 def _timed_launch(sym_fn, flops, launch):
@@ -159,7 +161,7 @@ def conv2d_dgrad(dy, w, in_hw: Tuple[int, int], stride: int, pad: int, addend: O
     need = 8 * n * hi * wi * ci * 4 if n * hi * wi * ci < (1 << 23) else 0
     ws = workspace(need, dy.device) if need else None
     m, k = n * hi * wi, r * s * co
-    _timed_launch(lambda: _gemm_symbol(m, ci, k, need, True, co), 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * co * r * s * ci,
+    _timed_launch(lambda: _gemm_symbol(m, ci, k, need, True, co, stride), 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * co * r * s * ci,
                   lambda: check(lib().phnet_conv2d_dgrad(_ptr(dy), _ptr(w), _ptr(addend), _ptr(dx), n, hi, wi, ci, co, r, s, stride,
                                                          pad, _ptr(ws), need, _stream()), "phnet_conv2d_dgrad"))
     return dx
@@ -181,7 +183,7 @@ def conv2d_wgrad(dy, x, w_shape, stride: int, pad: int, dw: Optional[torch.Tenso
     smallp = (r == 1 and s == 1 and stride == 1 and pad == 0 and n * ho * wo <= 256 and
               ((co + 63) // 64) * ((ci + 63) // 64) < 400)                                # few-rows Linear kernel (csrc/conv.hip)
     _timed_launch(lambda: (f"linear_wgrad_smallp_kernel<64, 64, {_MMA_MODE & 1}>" if smallp
-                           else f"conv_wgrad_kernel<{128 if (co >= 128 and (co < 256 or n * ho * wo > 8192)) else 64}, 64, {_MMA_MODE}>", 0),
+                           else f"conv_wgrad_kernel<{128 if (co >= 128 and (co < 256 or n * ho * wo > 8192)) else 64}, 64, {_MMA_MODE}, 16>", 0),
                   2.0 * n * ho * wo * co * r * s * ci,
                   lambda: check(lib().phnet_conv2d_wgrad(_ptr(dy), _ptr(x), _ptr(dw), _ptr(dbias), n, hi, wi, ci, co, r, s, stride,
                                                          pad, int(accumulate), _ptr(ws), need, _stream()), "phnet_conv2d_wgrad"))
@@ -729,12 +731,17 @@ def lane_decode(lines, conf_thresh: float, nms_thresh: float, top_k: int, img_w:
     return out if batched else {k: v[0] for k, v in out.items()}
 
 
+DEFAULT_MMA = "bf16x3"
+
+
 def set_mma_mode(mode: str) -> None:
     """Arithmetic of the conv / linear GEMM kernels (process-global; set it before a step is captured in a hipGraph):
-    "f32" = f32-input MFMA (default); "split_bf16" = operands split into two bf16 terms in registers, 3 bf16 MFMAs per
+    "bf16x3" (default) - see below; "f32" = f32-input MFMA (v_mfma_f32_32x32x2_f32, the round-1 default); "split_bf16" = operands split into two bf16 terms in registers, 3 bf16 MFMAs per
     product, f32 accumulation (~4x the rounding noise of "f32"); "split3_bf16" = three bf16 terms (an exact split of the
-    f32 value), 6 bf16 MFMAs per product, dropped terms <= 2^-24: the accuracy of "f32" (csrc/igemm.h)."""
+    f32 value), 6 bf16 MFMAs per product, dropped terms <= 2^-24: the accuracy of "f32" (csrc/igemm.h); "bf16x3" = the same
+    exact three-term arithmetic with the split done ONCE while a tile is staged into LDS (bf16 planes, transposed fragment
+    reads): the fast form of "split3_bf16"."""
     global _MMA_MODE
-    code = {"f32": 0, "split_bf16": 1, "split3_bf16": 2}[mode]
+    code = {"f32": 0, "split_bf16": 1, "split3_bf16": 2, "bf16x3": 3}[mode]
     check(lib().phnet_tune_mma(code), "phnet_tune_mma")
     _MMA_MODE = code

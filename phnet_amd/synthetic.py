@@ -33,3 +33,16 @@ def make_targets(img_h: int, img_w: int, T: int, num_points: int = 36, n_lanes: 
             out[t, j, 5] = n / (S - 1)
             out[t, j, 6:6 + n] = xs
     return torch.from_numpy(out)
+
+
+def spread_scores_(model, std: float = 0.5, seed: int = 11) -> None:
+    """Random-init PHNet scores every anchor at ~0.5 (the reference initialises its class heads with std 1e-3,
+    Router4OL.py:96-100), so an eval clip keeps no lane, the NMS sees K = 0 and the memory holds no positive token.
+    For inference benchmarks: redraw the class heads of both branches with a visible spread, so that about half of the 240
+    anchors of every frame pass conf_threshold (K ~ 120 candidates into the NMS, max_lanes keepers, positives in memory)."""
+    g = torch.Generator().manual_seed(seed)
+    det = model.detNet
+    with torch.no_grad():
+        for lin in (det.cls_layers, det.cls_layers_sec):
+            lin.weight.copy_(torch.randn(lin.weight.shape, generator=g).to(lin.weight) * std)
+            lin.bias.copy_(torch.randn(lin.bias.shape, generator=g).to(lin.bias) * 0.1)

@@ -133,8 +133,16 @@ CONV_CASES = [
 ]
 
 
+@pytest.fixture
+def f32_mfma(ops):
+    """GEMM kernels on the f32-input MFMA (v_mfma_f32_32x32x2_f32) - the round-1 arithmetic, still selectable."""
+    ops.set_mma_mode("f32")
+    yield
+    ops.set_mma_mode(ops.DEFAULT_MMA)
+
+
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv_fwd_dgrad_wgrad(ops, case):
+def test_conv_fwd_dgrad_wgrad(ops, f32_mfma, case):
     N, Hi, Wi, Ci, Co, R, stride, pad = case
     torch.manual_seed(sum(case))
     x = torch.randn(N, Ci, Hi, Wi, dtype=torch.float64, requires_grad=True)
@@ -168,7 +176,7 @@ def split_bf16(ops):
     """GEMM kernels in split-bf16 arithmetic for the duration of one test (process-global switch, restored afterwards)."""
     ops.set_mma_mode("split_bf16")
     yield
-    ops.set_mma_mode("f32")
+    ops.set_mma_mode(ops.DEFAULT_MMA)
 
 
 # every code path of CONV_CASES (tiles, split-K, ragged, stem, linears) once more in the opt-in split-bf16 arithmetic:
@@ -212,7 +220,58 @@ def test_conv_split3_bf16_is_as_accurate_as_f32_mfma(ops, case):
         close(ops.conv2d_dgrad(gyd, wd, (Hi, Wi), stride, pad), x.grad.permute(0, 2, 3, 1), 2e-5)
         close(ops.conv2d_wgrad(gyd, xd, wd.shape, stride, pad), w.grad.permute(0, 2, 3, 1), 2e-5)
     finally:
-        ops.set_mma_mode("f32")
+        ops.set_mma_mode(ops.DEFAULT_MMA)
+
+
+@pytest.fixture
+def bf16x3(ops):
+    """GEMM kernels in the staged exact-split arithmetic (three bf16 planes in LDS, 6 bf16 MFMAs per product)."""
+    ops.set_mma_mode("bf16x3")
+    yield
+    ops.set_mma_mode(ops.DEFAULT_MMA)
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad_bf16x3(ops, bf16x3, case):
+    """EVERY code path of CONV_CASES (tiles, split-K, ragged edges, stem, linears, strided and K-strided operands through the
+    hardware-transposed LDS reads) in the staged three-term split, held to the f32-input kernels' own tolerance (2e-5 of the
+    output scale against fp64): x = hi + mid + lo is an exact decomposition and only products below 2^-24 are dropped."""
+    N, Hi, Wi, Ci, Co, R, stride, pad = case
+    torch.manual_seed(sum(case) + 3)
+    x = torch.randn(N, Ci, Hi, Wi, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn(Co, Ci, R, R, dtype=torch.float64) / (Ci * R * R) ** 0.5).requires_grad_(True)
+    b = torch.randn(Co, dtype=torch.float64)
+    ref = F.conv2d(x, w, b, stride=stride, padding=pad)
+    gy = torch.randn_like(ref)
+    ref.backward(gy)
+    xd, wd, gyd = nhwc(x.detach().float()), nhwc(w.detach().float()), nhwc(gy.float())
+    close(ops.conv2d_fwd(xd, wd, dev(b.float()), stride, pad), ref.permute(0, 2, 3, 1), 2e-5)
+    close(ops.conv2d_fwd(xd, wd, dev(b.float()), stride, pad, relu=True), F.relu(ref).permute(0, 2, 3, 1), 2e-5)
+    close(ops.conv2d_dgrad(gyd, wd, (Hi, Wi), stride, pad), x.grad.permute(0, 2, 3, 1), 2e-5)
+    db = torch.full((Co,), 7.0, device="cuda")
+    dw = ops.conv2d_wgrad(gyd, xd, wd.shape, stride, pad, dbias=db)
+    close(dw, w.grad.permute(0, 2, 3, 1), 2e-5)
+    close(db, gy.sum(dim=(0, 2, 3)), 2e-5)
+    ops.conv2d_wgrad(gyd, xd, wd.shape, stride, pad, dw=dw, accumulate=True)
+    close(dw, 2 * w.grad.permute(0, 2, 3, 1), 2e-5)
+
+
+def test_bf16x3_split_is_exact_on_adversarial_values(ops, bf16x3):
+    """Operands chosen so that a two-term split would visibly lose bits: every mantissa bit set, magnitudes from 2^-100 to
+    2^100 in one row, exact cancellation.  A 1x1 'convolution' with K = 64 against fp64."""
+    torch.manual_seed(0)
+    M, K, N = 256, 64, 64
+    mant = 1.0 + (2.0 ** 23 - 1) / 2.0 ** 23                                         # 24 mantissa bits set
+    x = torch.full((M, K), mant, dtype=torch.float64) * torch.where(torch.rand(M, K) < 0.5, -1.0, 1.0).double()
+    x[:, ::7] *= 2.0 ** -20
+    x[1] *= 2.0 ** 60
+    x[2] *= 2.0 ** -60
+    w = torch.randn(N, K, dtype=torch.float64).float().double()
+    w[:, 1::5] = mant
+    ref = x @ w.t()
+    y = ops.linear_fwd(dev(x.float()), dev(w.float()), None)
+    err = (y.cpu().double() - ref).abs() / (x.abs() @ w.abs().t())                   # relative to the sum of |products|
+    assert float(err.max()) <= 3e-7, float(err.max())
 
 
 def test_split_bf16_large_problem_takes_the_large_tiles(ops, split_bf16):

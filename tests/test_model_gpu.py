@@ -54,6 +54,8 @@ def _close(a, b, tol=ACT_TOL, what="", ulp_floor=0.0):
     a = torch.as_tensor(a).detach().cpu().double()
     b = torch.as_tensor(b).detach().cpu().double()
     assert a.shape == b.shape, (what, a.shape, b.shape)
+    if b.numel() == 0:
+        return
     err = (a - b).abs()
     bound = tol * (1.0 + b.abs()) + ulp_floor * 2.0 ** -23 * float(b.abs().max())
     bad = err > bound
@@ -194,7 +196,12 @@ def _eval_case(g, T, gold_file, pts_atol=ACT_TOL):
 
 
 def test_tiny_train_parity_vs_reference_goldens():
-    _train_case(O.Geometry(img_h=64, img_w=160, arch="resnet18"), 3, "tiny_r18_64x160.npz", "grad_names_resnet18.json")
+    """(Sampled gradient entries at 1 % of the tensor's RMS entry: in the default bf16x3 arithmetic ONE sampled entry of one
+    BatchNorm bias - layer1.1.bn2.bias[0], 1.5e-4 in a tensor of O(0.3) entries - lands 2.5e-3 from the golden, cascade
+    noise of the module docstring; the f32-input MFMA holds 0.5 % on the same case, test_tiny_parity_on_the_f32_input_mfma.
+    Gradient NORMS are held to 5e-3 in both.)"""
+    _train_case(O.Geometry(img_h=64, img_w=160, arch="resnet18"), 3, "tiny_r18_64x160.npz", "grad_names_resnet18.json",
+                grad_rms_atol=1e-2)
 
 
 def test_tiny_ragged_targets_parity_vs_reference_goldens():
@@ -270,7 +277,7 @@ def split3_bf16():
     from phnet_amd import hip_ops
     hip_ops.set_mma_mode("split3_bf16")
     yield
-    hip_ops.set_mma_mode("f32")
+    hip_ops.set_mma_mode(hip_ops.DEFAULT_MMA)
 
 
 def test_config2_parity_in_split3_bf16_arithmetic(split3_bf16):
@@ -282,6 +289,31 @@ def test_config2_parity_in_split3_bf16_arithmetic(split3_bf16):
     _train_case(O.Geometry(arch="resnet34"), 5, "config2_r34_320x800.npz", "grad_names_resnet34.json",
                 grad_rtol=5e-2, grad_rms_atol=1e-1)
     _eval_case(O.Geometry(arch="resnet34"), 5, "config2_r34_320x800.npz")
+
+
+@pytest.fixture
+def f32_mfma():
+    from phnet_amd import hip_ops
+    hip_ops.set_mma_mode("f32")
+    yield
+    hip_ops.set_mma_mode(hip_ops.DEFAULT_MMA)
+
+
+def test_config2_parity_on_the_f32_input_mfma(f32_mfma):
+    """The round-1 arithmetic (hip_ops.set_mma_mode("f32"): v_mfma_f32_32x32x2_f32, bit-for-bit an fmaf chain) stays
+    selectable and holds the same goldens at the same tolerances as the default exact three-term bf16 split ("bf16x3": bf16
+    planes staged in LDS, 6 bf16 MFMAs per product, 4-deep register prefetch ring, buffer loads), which every other test of
+    this file runs in: train and eval at the headline configuration plus the strict per-stage teacher-forced check."""
+    _train_case(O.Geometry(arch="resnet34"), 5, "config2_r34_320x800.npz", "grad_names_resnet34.json",
+                grad_rtol=5e-2, grad_rms_atol=1e-1)
+    _eval_case(O.Geometry(arch="resnet34"), 5, "config2_r34_320x800.npz")
+    test_every_stage_teacher_forced_vs_oracle("config2", True)
+
+
+def test_tiny_parity_on_the_f32_input_mfma(f32_mfma):
+    _train_case(O.Geometry(img_h=64, img_w=160, arch="resnet18"), 3, "tiny_r18_64x160.npz", "grad_names_resnet18.json")
+    _eval_case(O.Geometry(img_h=64, img_w=160, arch="resnet18"), 4, "tiny_r18_64x160.npz")
+    _eval_case(O.Geometry(arch="resnet18"), 1, "config1_r18_320x800.npz")
 
 
 def test_eval_parity_in_split_bf16_arithmetic():
@@ -296,7 +328,7 @@ def test_eval_parity_in_split_bf16_arithmetic():
         _eval_case(O.Geometry(img_h=64, img_w=160, arch="resnet18"), 4, "tiny_r18_64x160.npz", pts_atol=2e-3)
         _eval_case(O.Geometry(arch="resnet18"), 1, "config1_r18_320x800.npz", pts_atol=2e-3)
     finally:
-        hip_ops.set_mma_mode("f32")
+        hip_ops.set_mma_mode(hip_ops.DEFAULT_MMA)
 
 
 def test_split_bf16_arithmetic_tracks_the_default_arithmetic():
@@ -314,7 +346,7 @@ def test_split_bf16_arithmetic_tracks_the_default_arithmetic():
     frames, lanes = synth.make_clip(g, T).cuda(), synth.make_targets(g, T).cuda()
     out = {}
     try:
-        for mode in ("f32", "split_bf16"):
+        for mode in ("f32", "split_bf16"):         # (baseline: the f32-input MFMA)
             hip_ops.set_mma_mode(mode)
             model = _build(g)
             model.train()
@@ -325,7 +357,7 @@ def test_split_bf16_arithmetic_tracks_the_default_arithmetic():
             undo()
             out[mode] = (float(loss.detach()), {k: float(p.grad.double().norm()) for k, p in model.named_parameters() if p.grad is not None}, rec)
     finally:
-        hip_ops.set_mma_mode("f32")
+        hip_ops.set_mma_mode(hip_ops.DEFAULT_MMA)
     (l0, g0, _), (l1, g1, rec) = out["f32"], out["split_bf16"]
     _close(rec["gate"][0][0], gold["train_gate"][0][0], what="gate t=0 stage 0")
     _close_lines(rec["fir"][0][0], gold["train_fir"][0][0], what="fir t=0 stage 0")
@@ -643,17 +675,18 @@ def test_workspace_growth_after_graph_capture_keeps_the_graph_valid():
     graph = GraphedInference(model, frames)
     rows0, nums0, anch0 = [t.clone() for t in graph(frames)]
     before = {k: v.data_ptr() for k, v in K._WS.items()}
-    # a much larger problem in the same process: every scratch slot has to grow
-    x = torch.randn(8, 96, 240, 64, device="cuda")
+    # every scratch slot is outgrown (what a larger problem in the same process does - eval with more clips, a larger
+    # resolution, a second graph at a larger shape), then ops that use the new buffers run
+    n_retired = len(K._WS_RETIRED)
+    for (dev_index, slot), buf in list(K._WS.items()):
+        K.workspace(2 * buf.numel() + 1, torch.device("cuda", dev_index), slot)
+    x = torch.randn(2, 24, 40, 64, device="cuda")
     w = torch.randn(64, 3, 3, 64, device="cuda") * 0.05
     y = K.conv2d_fwd(x, w, None, 1, 1)
     K.conv2d_wgrad(torch.randn_like(y), x, (64, 3, 3, 64), 1, 1)
     K.bn_fwd(y, torch.ones(64, device="cuda"), torch.zeros(64, device="cuda"), None, None, True, 1e-5, 0.1, None, True)
-    K.layernorm_bwd(torch.randn(4096, 2304, device="cuda"), torch.randn(4096, 2304, device="cuda"), None,
-                    torch.ones(2304, device="cuda"), torch.zeros(4096, device="cuda"), torch.ones(4096, device="cuda"), False)
     grown = [k for k, v in K._WS.items() if k in before and v.data_ptr() != before[k]]
-    assert grown, "the large problem was supposed to outgrow at least one scratch buffer"
-    assert len(K._WS_RETIRED) >= len(grown)
+    assert len(grown) == len(before) and len(K._WS_RETIRED) >= n_retired + len(grown)
     sentinels = [torch.full((1 << 20,), 7.0, device="cuda") for _ in range(8)]        # would land in freed scratch memory
     rows1, nums1, anch1 = graph(frames)
     torch.cuda.synchronize()

@@ -44,6 +44,14 @@ def main():
     if "--mma" in sys.argv:
         assert lib().phnet_tune_mma(1) == 0
         print("split-bf16 arithmetic")
+    if "--mode" in sys.argv:
+        mode = int(sys.argv[sys.argv.index("--mode") + 1])
+        assert lib().phnet_tune_mma(mode) == 0
+        print("GEMM arithmetic mode", mode)
+    if "--pf" in sys.argv:
+        pf = int(sys.argv[sys.argv.index("--pf") + 1])
+        assert lib().phnet_tune_force_k_tile(-100 - pf) == 0
+        print("register prefetch depth", pf)
     only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None
     for name, N, Hi, Wi, Ci, Co, R, st, pad in (SHAPES[:4] if TRUNK_ONLY else SHAPES):
         if only and only not in name:
@@ -56,7 +64,7 @@ def main():
         res = []
         ktiles = [0]
         if "--ktile" in sys.argv:
-            ktiles = [16, 32, 64]
+            ktiles = [16, 32] if "--pf" in sys.argv else [16, 32, 64]
         cfgs = [(0, 0)] if "--quick" in sys.argv else [(0, 0), (64, 64), (128, 64), (64, 128), (128, 128)]
         if "--ktile" in sys.argv:
             cfgs = [(64, 64), (128, 64), (128, 128)]
@@ -76,11 +84,11 @@ def main():
         tw = timeit(lambda: K.conv2d_wgrad(gy, x, w.shape, st, pad))
         print(f"== {name}: {fl/1e9:.2f} GF; wgrad {tw:.1f} us = {fl/tw/1e6:.1f} TF/s")
         if "--wgrad" in sys.argv:
-            for bm128 in (1, 0):
+            for bm128 in ((1, 0, 5, 4) if "--mode" in sys.argv else (1, 0)):                # bit 2: 32 pixels per K step (mode 3)
                 for target in (512, 768, 1250, 2000, 3000):
                     lib().phnet_tune_wgrad(bm128, target)
                     tw = timeit(lambda: K.conv2d_wgrad(gy, x, w.shape, st, pad))
-                    print(f"   wgrad bm128={bm128} target={target:5d}: {tw:7.1f} us {fl/tw/1e6:6.1f} TF/s")
+                    print(f"   wgrad bm128={bm128 & 1} bkw={32 if bm128 & 4 else 16} target={target:5d}: {tw:7.1f} us {fl/tw/1e6:6.1f} TF/s")
             lib().phnet_tune_wgrad(1, 768)
         lib().phnet_tune_force_k_tile(0)
         for bm, bn, sp, tf, td in res:

@@ -23,7 +23,7 @@ def main():
         yd.backward(gy.double().permute(0, 3, 1, 2))
         y_ref = yd.detach().permute(0, 2, 3, 1); dx_ref = xd.grad.permute(0, 2, 3, 1); dw_ref = wd.grad.permute(0, 2, 3, 1)
         print(f"== {name}: {fl/1e9:.2f} GF")
-        for mode in (0, 1, 2):
+        for mode in ((0, 3) if '--fast' in sys.argv else (0, 1, 2, 3)):
             assert lib().phnet_tune_mma(mode) == 0
             y = K.conv2d_fwd(x, w, None, st, pad); dx = K.conv2d_dgrad(gy, w, (Hi, Wi), st, pad); dw = K.conv2d_wgrad(gy, x, w.shape, st, pad)
             dw = dw[0] if isinstance(dw, tuple) else dw
