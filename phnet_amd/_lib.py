@@ -7,7 +7,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "lib", "libphnet_hip.so")
+SO_PATH = os.environ.get("PHNET_LIB") or os.path.join(_HERE, "lib", "libphnet_hip.so")      # PHNET_LIB: kernel experiments only
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "phnet_hip.h")
 
 _CTYPES = {"int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "uint64_t": ctypes.c_uint64,

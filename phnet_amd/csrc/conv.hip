@@ -23,6 +23,9 @@
 #define PHNET_INTERLEAVE 1
 #endif
 static constexpr bool g_interleave = PHNET_INTERLEAVE != 0;
+#ifdef PHNET_STAMPS              /* diagnostic build only: per-phase cycle stamps of the GEMM loop (tests/tools/stamps.py) */
+__device__ unsigned long long g_stamps[8];
+#endif
 
 using namespace igemm;
 
@@ -364,10 +367,26 @@ __device__ __forceinline__ void igemm_tile(
         // one iteration: slot U was emptied an iteration ago and takes tile tt + PF; tile tt (in LDS) is multiplied; tile
         // tt + 1 moves from its slot to the other LDS buffer.  Straight-line code (no branch between the loads and their use:
         // hipcc answers a branch with s_waitcnt vmcnt(0), which would drain the whole ring every iteration).
+#ifdef PHNET_STAMPS
+        unsigned long long st_load = 0, st_mma = 0, st_fill = 0, st_bar = 0;
+#define PHNET_STAMP(var, t_prev) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+                                      var += now_ - t_prev; t_prev = now_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define PHNET_STAMP(var, t_prev) do { } while (0)
+#endif
         auto iteration = [&](auto U, int tt) {
             constexpr int u = decltype(U)::value;
+#ifdef PHNET_STAMPS
+            __builtin_amdgcn_sched_barrier(0);
+            unsigned long long tprev = __builtin_amdgcn_s_memtime();
+#endif
             load_global(k_begin + (tt + PF) * BKT, a_set[u], b_set[u], r_set[u], mask_set[u]);
+            PHNET_STAMP(st_load, tprev);
             multiply_tile(buf, k_begin + tt * BKT);
+#ifdef PHNET_STAMPS
+            { float sink_; asm volatile("v_mov_b32 %0, %1" : "=v"(sink_) : "v"(acc[0][0][0])); asm volatile("" :: "v"(sink_)); }
+#endif
+            PHNET_STAMP(st_mma, tprev);
             // keep the LDS fill (and the wait for the global loads in front of it) BEHIND the MFMAs: left alone, the
             // scheduler hoists it above them - the operands are already in registers - and every wave then sits out its
             // full load latency before it issues a single MFMA
@@ -376,6 +395,10 @@ __device__ __forceinline__ void igemm_tile(
             if (PF == 1) __builtin_amdgcn_sched_barrier(0);
             constexpr int v = (u + 1) % PF;
             store_lds(buf ^ 1, a_set[v], b_set[v], r_set[v], mask_set[v]);
+#ifdef PHNET_STAMPS
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+            PHNET_STAMP(st_fill, tprev);
             if (PF > 1 && S3 && g_interleave) {
                 // one MFMA, then a handful of the next tile's split / address instructions, ...: the matrix pipe takes an MFMA
                 // every 32 cycles and blocks the vector issue for 8 of them
@@ -386,11 +409,18 @@ __device__ __forceinline__ void igemm_tile(
                 }
             }
             __syncthreads();
+            PHNET_STAMP(st_bar, tprev);
             buf ^= 1;
         };
         int t = 0;
         for (; t + PF <= ntiles; t += PF) unroll_iterations<PF>(iteration, t);
         if (PF > 1) tail_iterations<PF - 1>(iteration, t, ntiles);
+#ifdef PHNET_STAMPS
+        if (lane == 0) {
+            atomicAdd(&g_stamps[0], st_load); atomicAdd(&g_stamps[1], st_mma); atomicAdd(&g_stamps[2], st_fill);
+            atomicAdd(&g_stamps[3], st_bar); atomicAdd(&g_stamps[4], (unsigned long long)ntiles);
+        }
+#endif
     }
 
     // ---- epilogue: bias / relu, or raw partial sums when split-K --------------------------------
@@ -859,7 +889,7 @@ TileChoice pick_tile(long M, long N)
     // Measured on MI355X (tests/tools/bench_conv.py): the problems of this path are small (a 5-frame clip), so what
     // matters is the number of co-resident workgroups per CU, not the tile's arithmetic intensity: 64x64 tiles with
     // the block count topped up to ~1250 by split-K beat the larger tiles on every trunk layer (72-80 us vs 85-130 us).
-    if (g_mma_mode == 3 && M <= 2048) return {64, 64};          // few-rows GEMMs run K tile 64: 110 KB of LDS with 64x64 tiles
+    if (g_mma_mode == 3 && M <= 1216) return {64, 64};          // few-rows GEMMs run K tile 64: 110 KB of LDS with 64x64 tiles
     if (g_mma_mode >= 1) {
         // split-bf16: the loop is bound by the operand split (VALU) and the LDS reads per MFMA, both of which shrink with
         // the wave tile - problems with enough tiles take the larger ones (bench_conv.py --mma --clips 8: 128x128 is
@@ -876,7 +906,7 @@ struct ConvPlan { int bm, bn, splits; long tiles; };
 // (the MFMA work per barrier is 5x shorter there; measured 44-54 us vs 51-58 us on the trunk layers)
 int k_tile_for(long M, int K, int ci, int bm, int bn)
 {
-    if (M <= 2048 && K >= 64) return (g_mma_mode == 3 && g_deep_kt3 == 32) ? 32 : 64;
+    if (M <= 1216 && K >= 64) return (g_mma_mode == 3 && g_deep_kt3 == 32) ? 32 : 64;    // (up to 5 x 240 rows: the lane head; not layer4's 1250 pixels)
     if (g_mma_mode == 3) return BK;                                   // 37 KB of LDS per 64x64 workgroup: four per CU
     if (g_mma_mode >= 1 && bm == 64 && bn == 64 && ci % 32 == 0) return 32;
     return BK;
@@ -905,7 +935,7 @@ ConvPlan plan_conv(long M, int Co, int K, bool has_ws, size_t ws_bytes)
     // split K until ~1250 workgroups are in flight (about 5 per CU), keeping >= 256 of K per split
     // K-tile-64 plans (M <= 2048: the head GEMMs) hold 70 KB of LDS per workgroup = 2 workgroups per CU, so ~512 tiles already
     // fill the chip in one round and a split only adds the reduce pass (hyper-net 1024 -> 8192 at 240 rows: 54 vs 62 us)
-    const bool deep = M <= 2048 && K >= 64;
+    const bool deep = M <= 1216 && K >= 64;
     if (has_ws && p.tiles < (deep ? 400 : 900)) {
         int splits = (int)min((long)8, max((long)1, (1250 + p.tiles / 2) / p.tiles));
         while (splits > 1 && K / splits < 256) --splits;
@@ -1019,6 +1049,15 @@ PHNET_API int phnet_tune_wgrad(int32_t allow_bm128, int32_t target_blocks)
     g_wgrad_target = target_blocks;
     return PHNET_OK;
 }
+
+#ifdef PHNET_STAMPS
+PHNET_API int phnet_debug_stamps(unsigned long long* out, int reset)
+{
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 8) != hipSuccess) return PHNET_ERR_LAUNCH;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)) != hipSuccess) return PHNET_ERR_LAUNCH; }
+    return PHNET_OK;
+}
+#endif
 
 // Tuning aid (process-global): arithmetic of the GEMM kernels.  0 = f32-input MFMA (default), 1 = split-bf16 (igemm.h).
 PHNET_API int phnet_tune_mma(int32_t mode)
