@@ -488,7 +488,8 @@ struct WgradShape {
 
 // out: dW itself when g.splits == 1 (written or accumulated in the epilogue) else the split-K partial buffer
 // [splits][Co*NC + Co] (the trailing Co floats of every split hold its bias-gradient partial).
-template <int BM, int BN, int MMA = 0, int BKW = BK>
+// PF / BUF: register prefetch ring and buffer loads as in igemm_tile (used by the staged-split arithmetic)
+template <int BM, int BN, int MMA = 0, int BKW = BK, int PF = 1, bool BUF = false>
 __global__ __launch_bounds__(THREADS) void conv_wgrad_kernel(
     const float* __restrict__ dY, const float* __restrict__ X, float* __restrict__ out, float* __restrict__ dbias,
     WgradShape g, int want_bias, int accumulate)
@@ -552,24 +553,68 @@ __global__ __launch_bounds__(THREADS) void conv_wgrad_kernel(
         a_ch[i] = (idx - a_kk[i] * (BM / 4)) * 4;
     }
 
-    f32x4 a_reg[A_LOADS], b_reg[B_LOADS], bsum[A_LOADS];
+    f32x4 a_set[PF][A_LOADS], b_set[PF][B_LOADS], bsum[A_LOADS];
+    unsigned m_set[PF];
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i) bsum[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // ---- BUF: 32-bit byte offsets, out-of-range elements pushed past the end of the tensor (the hardware returns zeros) ----
+    constexpr unsigned OOB = 0x80000000u;
+    __amdgpu_buffer_rsrc_t y_rsrc, x_rsrc;
+    int a_off[BUF ? A_LOADS : 1];
+    float inv_wo = 0.f, inv_ho = 0.f;
+    if constexpr (BUF) {
+        y_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)dY, 0, (int)min((long)P * g.Co * 4, (long)0x7fffffff), 0x00020000);
+        x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)min((long)g.N * g.Hi * g.Wi * g.Ci * 4, (long)0x7fffffff), 0x00020000);
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) a_off[i] = m0 + a_ch[i] < g.Co ? (a_kk[i] * g.Co + m0 + a_ch[i]) * 4 : (int)OOB;
+        inv_wo = 1.0f / (float)g.Wo; inv_ho = 1.0f / (float)g.Ho;
+    }
     const bool bias_block = want_bias && n0 == 0;            // the first column tile also sums dY over the pixels
     // loads the K step that starts at pixel pt; MUST be called with pt = p_begin, p_begin+BK, ... in order
     // branch-free loads (masked chunks read element 0 and are zeroed on the LDS write): straight-line code, exact s_waitcnt
-    unsigned lmask = 0;
-    auto load_global = [&](int pt, bool advance) {
+    auto load_global = [&](int pt, bool advance, f32x4 (&a_reg)[A_LOADS], f32x4 (&b_reg)[B_LOADS], unsigned& lmask) {
         lmask = 0;
         if (advance) {                                   // pixel carry of the B gather: BEFORE the loads, so that nothing but
 #pragma unroll                                           // straight-line code sits between them and the MFMAs
             for (int i = 0; i < B_LOADS; ++i) {
-                b_ox[i] += BKW;
-                while (b_ox[i] >= g.Wo) {
-                    b_ox[i] -= g.Wo;
-                    if (++b_oy[i] == g.Ho) { b_oy[i] = 0; ++b_n[i]; }
+                if constexpr (BUF) {
+                    // branch-free (a branch costs the ring an s_waitcnt vmcnt(0)): wraps = floor(ox / Wo) by a float reciprocal
+                    // (exact after one correction step for ox < 2^22), then the same for the rows
+                    int ox = b_ox[i] + BKW;
+                    int w = (int)((float)ox * inv_wo);
+                    ox -= w * g.Wo;
+                    const int lo = ox < 0, hi = ox >= g.Wo;
+                    ox += lo ? g.Wo : 0; ox -= hi ? g.Wo : 0; w += hi - lo;
+                    int oy = b_oy[i] + w;
+                    int v = (int)((float)oy * inv_ho);
+                    oy -= v * g.Ho;
+                    const int lo2 = oy < 0, hi2 = oy >= g.Ho;
+                    oy += lo2 ? g.Ho : 0; oy -= hi2 ? g.Ho : 0; v += hi2 - lo2;
+                    b_ox[i] = ox; b_oy[i] = oy; b_n[i] += v;
+                } else {
+                    b_ox[i] += BKW;
+                    while (b_ox[i] >= g.Wo) {
+                        b_ox[i] -= g.Wo;
+                        if (++b_oy[i] == g.Ho) { b_oy[i] = 0; ++b_n[i]; }
+                    }
                 }
             }
+        }
+        if constexpr (BUF) {
+            const int s_a = pt * g.Co * 4;
+#pragma unroll
+            for (int i = 0; i < A_LOADS; ++i) {
+                const bool ok = pt + a_kk[i] < p_end;
+                a_reg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(y_rsrc, ok ? a_off[i] + s_a : (int)OOB, 0, 0));
+            }
+#pragma unroll
+            for (int i = 0; i < B_LOADS; ++i) {
+                const int iy = b_oy[i] * g.stride - g.pad + b_r[i], ix = b_ox[i] * g.stride - g.pad + b_q[i];
+                const bool ok = b_ok[i] && pt + b_kk[i] < p_end && (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi;
+                const int off = (((b_n[i] * g.Hi + iy) * g.Wi + ix) * g.Ci + b_c[i]) * 4;
+                b_reg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, ok ? off : (int)OOB, 0, 0));
+            }
+            return;
         }
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i) {
@@ -588,18 +633,18 @@ __global__ __launch_bounds__(THREADS) void conv_wgrad_kernel(
             lmask |= (unsigned)ok << (16 + i);
         }
     };
-    auto store_lds = [&](int buf) {
+    auto store_lds = [&](int buf, const f32x4 (&a_reg)[A_LOADS], const f32x4 (&b_reg)[B_LOADS], unsigned lmask) {
         const f32x4 zero{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i) {
-            const f32x4 v = (lmask >> i) & 1u ? a_reg[i] : zero;
+            const f32x4 v = BUF ? a_reg[i] : ((lmask >> i) & 1u ? a_reg[i] : zero);
             if (bias_block) bsum[i] += v;
             if (S3) store_split3<AP3::PLANE>(A3 + buf * AP3::BYTES, a_kk[i] * AP3::PITCH + a_ch[i] * 2, v);
             else *reinterpret_cast<f32x4*>(As + buf * A_FLOATS + a_kk[i] * A_PITCH + a_ch[i]) = v;
         }
 #pragma unroll
         for (int i = 0; i < B_LOADS; ++i) {
-            const f32x4 v = (lmask >> (16 + i)) & 1u ? b_reg[i] : zero;
+            const f32x4 v = BUF ? b_reg[i] : ((lmask >> (16 + i)) & 1u ? b_reg[i] : zero);
             if (S3) store_split3<BP3::PLANE>(B3 + buf * BP3::BYTES, b_kk[i] * BP3::PITCH + b_col[i] * 2, v);
             else *reinterpret_cast<f32x4*>(Bs + buf * B_FLOATS + b_kk[i] * B_PITCH + b_col[i]) = v;
         }
@@ -622,12 +667,15 @@ __global__ __launch_bounds__(THREADS) void conv_wgrad_kernel(
             }
 
     if (p_begin < p_end) {
-        load_global(p_begin, false);
-        store_lds(0);
+        const int nsteps = (p_end - p_begin + BKW - 1) / BKW;
+#pragma unroll
+        for (int d = 0; d < PF; ++d) load_global(p_begin + d * BKW, d > 0, a_set[d], b_set[d], m_set[d]);
+        store_lds(0, a_set[0], b_set[0], m_set[0]);
         __syncthreads();
         int buf = 0;
-        for (int pt = p_begin; pt < p_end; pt += BKW) {
-            load_global(pt + BKW, true);                 // past the end: fully masked
+        auto iteration = [&](auto U, int tt) {
+            constexpr int u = decltype(U)::value;
+            load_global(p_begin + (tt + PF) * BKW, true, a_set[u], b_set[u], m_set[u]);       // past the end: fully masked
 #pragma unroll
             for (int ks = 0; ks < BKW / BK; ++ks) {
                 if (S3) {
@@ -642,11 +690,22 @@ __global__ __launch_bounds__(THREADS) void conv_wgrad_kernel(
                     mma_any<S3 ? 0 : MMA, FM, FN>(a, b, acc);
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);           // the LDS fill (and its wait for the loads) stays behind the MFMAs
-            store_lds(buf ^ 1);
+            if (PF == 1) __builtin_amdgcn_sched_barrier(0);           // the LDS fill (and its wait for the loads) stays behind the MFMAs
+            constexpr int v = (u + 1) % PF;
+            store_lds(buf ^ 1, a_set[v], b_set[v], m_set[v]);
+            if (PF > 1 && S3 && g_interleave) {
+#pragma unroll
+                for (int i = 0; i < 6 * FM * FN * (BKW / BK); ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, (14 + FM * FN - 1) / (FM * FN), 0);
+                }
+            }
             __syncthreads();
             buf ^= 1;
-        }
+        };
+        int t = 0;
+        for (; t + PF <= nsteps; t += PF) unroll_iterations<PF>(iteration, t);
+        if (PF > 1) tail_iterations<PF - 1>(iteration, t, nsteps);
     }
     const bool direct = g.splits == 1;
     float* dst = direct ? out : out + (size_t)blockIdx.z * ((size_t)g.Co * NC + g.Co);
@@ -1204,13 +1263,13 @@ PHNET_API int phnet_conv2d_wgrad(const float* dy, const float* x, float* dw, flo
     dim3 grid((unsigned)tiles, 1, (unsigned)splits);
     const int want_bias = dbias != nullptr;
     if (g_mma_mode == 3 && bkw == 32 && bm == 128)
-        hipLaunchKernelGGL((conv_wgrad_kernel<128, 64, 3, 32>), grid, dim3(THREADS), 0, st, dy, x, out, dbias, g, want_bias, accumulate);
+        hipLaunchKernelGGL((conv_wgrad_kernel<128, 64, 3, 32, 2, true>), grid, dim3(THREADS), 0, st, dy, x, out, dbias, g, want_bias, accumulate);
     else if (g_mma_mode == 3 && bkw == 32)
-        hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 3, 32>), grid, dim3(THREADS), 0, st, dy, x, out, dbias, g, want_bias, accumulate);
+        hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 3, 32, 2, true>), grid, dim3(THREADS), 0, st, dy, x, out, dbias, g, want_bias, accumulate);
     else if (g_mma_mode == 3 && bm == 128)
-        hipLaunchKernelGGL((conv_wgrad_kernel<128, 64, 3>), grid, dim3(THREADS), 0, st, dy, x, out, dbias, g, want_bias, accumulate);
+        hipLaunchKernelGGL((conv_wgrad_kernel<128, 64, 3, 16, 4, true>), grid, dim3(THREADS), 0, st, dy, x, out, dbias, g, want_bias, accumulate);
     else if (g_mma_mode == 3)
-        hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 3>), grid, dim3(THREADS), 0, st, dy, x, out, dbias, g, want_bias, accumulate);
+        hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 3, 16, 4, true>), grid, dim3(THREADS), 0, st, dy, x, out, dbias, g, want_bias, accumulate);
     else if (bm == 128 && g_mma_mode == 2)
         hipLaunchKernelGGL((conv_wgrad_kernel<128, 64, 2>), grid, dim3(THREADS), 0, st, dy, x, out, dbias, g, want_bias, accumulate);
     else if (g_mma_mode == 2)
