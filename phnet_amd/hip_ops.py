@@ -182,8 +182,8 @@ def conv2d_wgrad(dy, x, w_shape, stride: int, pad: int, dw: Optional[torch.Tenso
     ho, wo = conv_out_hw(hi, wi, r, s, stride, pad)
     smallp = (r == 1 and s == 1 and stride == 1 and pad == 0 and n * ho * wo <= 256 and
               ((co + 63) // 64) * ((ci + 63) // 64) < 400)                                # few-rows Linear kernel (csrc/conv.hip)
-    _timed_launch(lambda: (f"linear_wgrad_smallp_kernel<64, 64, {_MMA_MODE & 1}>" if smallp
-                           else f"conv_wgrad_kernel<{128 if (co >= 128 and (co < 256 or n * ho * wo > 8192)) else 64}, 64, {_MMA_MODE}, 16>", 0),
+    _timed_launch(lambda: (f"linear_wgrad_smallp_kernel<64, 64, {1 if _MMA_MODE == 1 else 0}>" if smallp
+                           else f"conv_wgrad_kernel<{128 if (co >= 128 and (co < 256 or n * ho * wo > 8192)) else 64}, 64, {_MMA_MODE}, 16, {4 if _MMA_MODE == 3 else 1}, {'true' if _MMA_MODE == 3 else 'false'}>", 0),
                   2.0 * n * ho * wo * co * r * s * ci,
                   lambda: check(lib().phnet_conv2d_wgrad(_ptr(dy), _ptr(x), _ptr(dw), _ptr(dbias), n, hi, wi, ci, co, r, s, stride,
                                                          pad, int(accumulate), _ptr(ws), need, _stream()), "phnet_conv2d_wgrad"))
@@ -221,7 +221,7 @@ def linear_bwd(dy2d, x2d, w, dw: torch.Tensor, dbias: Optional[torch.Tensor], ac
     m, n = dy2d.shape
     k = x2d.shape[1]
     dx = torch.empty((m, k), dtype=torch.float32, device=dy2d.device)
-    sym = f"linear_bwd_fused_kernel<{'true' if n % 64 == 0 else 'false'}, {'true' if relu_y is not None else 'false'}, {_MMA_MODE & 1}>"
+    sym = f"linear_bwd_fused_kernel<{'true' if n % 64 == 0 else 'false'}, {'true' if relu_y is not None else 'false'}, {1 if _MMA_MODE == 1 else 0}>"
     _timed_launch(lambda: (sym, 0), 4.0 * m * n * k,
                   lambda: check(lib().phnet_linear_bwd(_ptr(dy2d), _ptr(x2d), _ptr(w), _ptr(relu_y), _ptr(dx), _ptr(dw), _ptr(dbias), m, k, n,
                                                        int(accumulate), _stream()), "phnet_linear_bwd"))

@@ -350,6 +350,7 @@ class RouterOL(nn.Module):
         self.org_size = (cfg.dscfg.org_height, cfg.dscfg.org_width)
         self.sync_free_eval = True      # eval: fused device-side decode, one D2H copy per clip (False: per-frame get_lanes)
         self.batch_stage0 = True        # stage-0 ROI pooling / dynamic head / branch A of all frames in one batch
+        self.stage_major = True         # training: EVERY stage's frame-independent part batched over the frames (train_clip_stage_major)
 
     def _begin_clip(self):
         det = self.detNet
@@ -453,6 +454,55 @@ class RouterOL(nn.Module):
         self._begin_clip()
         return total_loss
 
+    def train_clip_stage_major(self, frame: torch.Tensor, lanes: torch.Tensor):
+        """Training forward of one clip in STAGE-major order.  What ties the frames of a clip together is only branch B's
+        memory: stage s of frame t attends to the stage-s tokens of the up to `save_freq_max` frames before it
+        (Router4OL.py:515-560), and those tokens are picked by the label assignment of that frame's OWN stage-s
+        predictions.  ROI pooling, routing gate, dynamic head and branch A of stage s depend on frame t alone (through the
+        stage-(s-1) blend).  So instead of 15 serial (frame, stage) iterations of ~40 launches on 240 rows, every stage runs
+        its frame-independent part ONCE for the whole clip (T*240 rows per kernel, as stage 0 already did) and only
+        branch B + the assignment + the token gather walk the frames.  Same arithmetic per (frame, stage); the matched
+        anchors that feed the memory come from the stand-alone assignment kernel (the criterion recomputes the identical
+        assignment later, tests/test_model_gpu.py)."""
+        from phnet_amd import hip_ops as K
+        det = self.detNet
+        T = frame.shape[0]
+        feats = self.backbone(frame)                                           # 3 x [T,h,w,C] NHWC
+        levels = list(feats)[::-1]
+        det.priors, det.priors_on_featmap = det.generate_priors_from_embeddings()
+        priors = det.priors.unsqueeze(0).expand(T, -1, -1)
+        on_map = det.priors_on_featmap.unsqueeze(0).expand(T, -1, -1).contiguous()
+        pro = det.pro_embedding.weight.unsqueeze(0).expand(T, -1, -1)
+        per_frame = [{"predictions_fir": [], "predictions_sec": [], "gates": []} for _ in range(T)]
+        for stage in range(det.refine_layers):
+            front = det.stage_front(levels[stage], stage, priors, on_map, pro)                 # everything [T,...]
+            parts = {k: v.split(1, dim=0) for k, v in front.items()}                          # one cat in the backward
+            pri_t = priors.split(1, dim=0) if priors.requires_grad else [priors[t:t + 1] for t in range(T)]
+            tokens, lines_b = [], []
+            for t in range(T):
+                window = tokens[max(0, t - self.save_freq_max):t]
+                mem = None
+                if window:
+                    mem = (torch.cat([w[0] for w in window], dim=0), torch.cat([w[1] for w in window], dim=0))
+                r = det.stage_back({k: parts[k][t] for k in parts}, stage, pri_t[t], mem)
+                with torch.no_grad():
+                    _, rows_sorted, _ = K.lane_assign(r["pred_b"][0].detach().contiguous(), lanes[t].contiguous(), det.img_w, det.img_h)
+                    tokens.append(self._tokens(r["attn"].detach(), rows_sorted))
+                per_frame[t]["predictions_fir"].append(r["pred_a"])
+                per_frame[t]["predictions_sec"].append(r["pred_b"])
+                per_frame[t]["gates"].append(r["gate"])
+                lines_b.append(r["lines_b"].detach())
+            if stage != det.refine_layers - 1:
+                priors, on_map = K.blend_priors(front["gate"].detach().contiguous(), front["lines_a"].detach().contiguous(),
+                                                torch.cat(lines_b, dim=0), det.sample_x_indexs)
+                pro = front["local"].detach()
+        total_loss = 0.0
+        for t in range(T):
+            out = {"predictions_fir": per_frame[t]["predictions_fir"], "predictions_sec": per_frame[t]["predictions_sec"]}
+            _, frame_loss = self.criterion(out, lanes[t:t + 1], per_frame[t]["gates"])
+            total_loss = total_loss + frame_loss
+        return total_loss
+
     def lanes_from_device(self, kept_rows: torch.Tensor, nums: torch.Tensor):
         """One device->host copy per clip, then the host-side Lane construction (Router4OL.py:394-435)."""
         rows, n = kept_rows.cpu(), nums.cpu().tolist()
@@ -475,6 +525,10 @@ class RouterOL(nn.Module):
         self._begin_clip()
         if self.training:
             PF.DropoutStream.begin_step(frame.device)                          # fresh dropout masks for this clip's fwd + bwd
+            if self.stage_major and self.batch_stage0:
+                loss = self.train_clip_stage_major(frame, lanes)
+                self._begin_clip()
+                return loss
         feats = self.backbone(frame)                                           # 3 x [T,h,w,C] NHWC
         last_cuts = []
         total_loss = 0.0
