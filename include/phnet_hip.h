@@ -68,6 +68,14 @@ int phnet_roi_pool_bwd(const float* dout, const float* fmap, const float* xs, co
 int phnet_conv2d_fwd(const float* x, const float* w, const float* bias, float* y,
                      int32_t N, int32_t Hi, int32_t Wi, int32_t Ci, int32_t Co, int32_t R, int32_t S,
                      int32_t stride, int32_t pad, int32_t relu, void* workspace, uint64_t ws_bytes, void* stream);
+/* forward with a fused epilogue: y = relu?(conv + bias + addend) (addend shaped like y: the residual branch of an eval-mode
+ * BatchNorm block whose scale / shift were folded into w / bias), and / or stats = per-channel (sum | sum of squares) partials
+ * of y for a following training-mode BatchNorm: phnet_conv2d_stats_blocks() rows of 2*Co floats, consumed by
+ * phnet_bn_finalize_partials (no separate statistics pass over y; needs bias == addend == NULL, relu == 0, Co = 2^k <= 1024). */
+uint64_t phnet_conv2d_stats_blocks(int64_t M, int32_t Co, int32_t K, uint64_t ws_bytes);
+int phnet_conv2d_fwd_fused(const float* x, const float* w, const float* bias, const float* addend, float* y, float* stats,
+                           int32_t N, int32_t Hi, int32_t Wi, int32_t Ci, int32_t Co, int32_t R, int32_t S,
+                           int32_t stride, int32_t pad, int32_t relu, void* workspace, uint64_t ws_bytes, void* stream);
 /* dx = dgrad(dy, w) (+ addend): addend is optional, shaped like dx, and may alias dx. */
 int phnet_conv2d_dgrad(const float* dy, const float* w, const float* addend, float* dx,
                        int32_t N, int32_t Hi, int32_t Wi, int32_t Ci, int32_t Co, int32_t R, int32_t S,
@@ -111,6 +119,10 @@ int phnet_bn_fwd_stats(const float* x, int64_t M, int32_t C, float eps, float mo
                        const float* gamma, const float* beta, float* running_mean, float* running_var,
                        float* save_mean, float* save_invstd, float* scale, float* shift,
                        float* partial, int32_t training, void* stream);
+/* the finalize half of phnet_bn_fwd_stats on partials somebody else produced (phnet_conv2d_fwd_fused): partial [nblk][2C] */
+int phnet_bn_finalize_partials(const float* partial, int64_t nblk, int64_t M, int32_t C, float eps, float momentum,
+                               const float* gamma, const float* beta, float* running_mean, float* running_var,
+                               float* save_mean, float* save_invstd, float* scale, float* shift, void* stream);
 int phnet_bn_apply(const float* x, const float* scale, const float* shift, const float* residual, float* y,
                    int64_t M, int32_t C, int32_t relu, void* stream);
 int phnet_bn_bwd(const float* dy, const float* x, const float* y, const float* save_mean,

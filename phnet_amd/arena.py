@@ -71,12 +71,32 @@ class _GradSink(torch.autograd.Function):
         return (ctx.buf if g is None else ctx.buf + g), None
 
 
-def grad_sink(w: torch.Tensor) -> torch.Tensor:
+class SinkPool:
+    """Zero-initialised side buffers for the grad sinks of ONE clip, carved out of a few large zero-filled chunks (one fill
+    launch per chunk instead of one per derived weight: 24 per clip).  A pool belongs to one forward pass - every clip gets
+    fresh buffers, so several forward passes before one backward (trainOL.py:205-212) still keep their gradients apart."""
+    CHUNK = 3 << 20                                     # floats; the derived weights of one clip need ~2.3 M
+
+    def __init__(self):
+        self.chunk, self.used = None, 0
+
+    def take(self, like: torch.Tensor) -> torch.Tensor:
+        n = like.numel()
+        pad = (-n) % 4
+        if self.chunk is None or self.chunk.device != like.device or self.used + n + pad > self.chunk.numel():
+            self.chunk = torch.zeros(max(self.CHUNK, n + pad), dtype=torch.float32, device=like.device)
+            self.used = 0
+        buf = self.chunk[self.used:self.used + n].view(like.shape)
+        self.used += n + pad
+        return buf
+
+
+def grad_sink(w: torch.Tensor, pool: Optional[SinkPool] = None) -> torch.Tensor:
     """Returns `w` as a tensor whose gradient is gathered in a zero-initialised side buffer (see _GradSink)."""
     if not (torch.is_grad_enabled() and w.requires_grad):
         return w
     w = w.contiguous()
-    buf = torch.zeros_like(w)
+    buf = pool.take(w) if (pool is not None and w.dtype == torch.float32) else torch.zeros_like(w)
     out = _GradSink.apply(w, buf)
     out._phnet_sink = buf
     return out

@@ -52,21 +52,35 @@ __device__ __forceinline__ void lane_assign_block(
         const float posc = -logf(pr + 1e-12f) * 0.25f * ((1.0f - pr) * (1.0f - pr));
         cls = posc - negc;
         const float psy = p[2] * (img_h - 1.0f), psx = p[3] * (img_w - 1.0f), pth = p[4];
+        // one pass over the anchor's S x-columns for all label columns at once (each x is read once, as a float2: the row
+        // starts at an even element) - the four per-column sums keep their ascending-k order
+        float d[MAXL], ovr[MAXL], uni[MAXL];
+#pragma unroll
+        for (int j = 0; j < MAXL; ++j) d[j] = ovr[j] = uni[j] = 0.f;
+        auto term = [&](int k, float xr) {
+            const float x = xr * (img_w - 1.0f);
+#pragma unroll
+            for (int j = 0; j < MAXL; ++j) {
+                const float t = t_x[j][k];
+                if (j >= L || !t_valid[j] || (t < 0.f) || (t >= img_w)) continue;
+                d[j] += fabsf(t - x);
+                ovr[j] += fminf(x + 15.f, t + 15.f) - fmaxf(x - 15.f, t - 15.f);
+                uni[j] += fmaxf(x + 15.f, t + 15.f) - fminf(x - 15.f, t - 15.f);
+            }
+        };
+        int k = 0;
+        if ((W & 1) == 0)
+            for (; k + 1 < S; k += 2) {
+                const float2 xx = *reinterpret_cast<const float2*>(p + 6 + k);
+                term(k, xx.x); term(k + 1, xx.y);
+            }
+        for (; k < S; ++k) term(k, p[6 + k]);
 #pragma unroll
         for (int j = 0; j < MAXL; ++j) {
             dist[j] = start[j] = theta[j] = iou[j] = 0.f;
             if (j >= L || !t_valid[j]) continue;
-            float d = 0.f, ovr = 0.f, uni = 0.f;
-            for (int k = 0; k < S; ++k) {
-                const float t = t_x[j][k];
-                if ((t < 0.f) || (t >= img_w)) continue;
-                const float x = p[6 + k] * (img_w - 1.0f);
-                d += fabsf(t - x);
-                ovr += fminf(x + 15.f, t + 15.f) - fmaxf(x - 15.f, t - 15.f);
-                uni += fmaxf(x + 15.f, t + 15.f) - fminf(x - 15.f, t - 15.f);
-            }
-            dist[j] = d / (t_len[j] + 1e-9f);
-            iou[j] = ovr / (uni + 1e-9f);
+            dist[j] = d[j] / (t_len[j] + 1e-9f);
+            iou[j] = ovr[j] / (uni[j] + 1e-9f);
             const float* tr = tgt + (size_t)j * W;
             const float dy = psy - tr[2] * (img_h - 1.0f), dx = psx - tr[3] * (img_w - 1.0f);
             start[j] = sqrtf(dy * dy + dx * dx);

@@ -77,7 +77,8 @@ template <int BM, int BN, bool B_DGRAD, int BKT, bool UNI, bool AMASK = false, i
 __device__ __forceinline__ void igemm_tile(
     const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ bias,
     const float* __restrict__ addend, float* __restrict__ out, const ConvShape& g, int relu,
-    float* lds, unsigned block, unsigned nblocks, unsigned split, const float* __restrict__ amask = nullptr)
+    float* lds, unsigned block, unsigned nblocks, unsigned split, const float* __restrict__ amask = nullptr,
+    float* __restrict__ stats = nullptr)
 {
     constexpr int TM = BM / 2, TN = BN / 2, FM = TM / 32, FN = TN / 32;
     constexpr int A_PITCH = KContigTile<BM, BKT>::PITCH;
@@ -423,6 +424,29 @@ __device__ __forceinline__ void igemm_tile(
 #endif
     }
 
+    // ---- per-channel statistics of the result (BatchNorm's batch statistics without a second pass over the tensor):
+    // every 32-row slab of the output writes its (sum, sum of squares) per column into stats[slab][2*Co]; rows past M are
+    // exact zeros (their A rows were zero and a convolution in front of a BatchNorm has no bias) -------------------
+    if (stats != nullptr && final_pass) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int n = n0 + wn + j * 32 + frag_col(lane);
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                float sm = 0.f, sq = 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { const float v = acc[i][j][e]; sm += v; sq += v * v; }
+                sm += __shfl_xor(sm, 32, 64);
+                sq += __shfl_xor(sq, 32, 64);
+                if (lane < 32 && n < g.Co) {
+                    float* p = stats + (size_t)((m0 + wm + i * 32) >> 5) * 2 * g.Co;
+                    p[n] = sm;
+                    p[g.Co + n] = sq;
+                }
+            }
+        }
+    }
+
     // ---- epilogue: bias / relu, or raw partial sums when split-K --------------------------------
     float* dst = out + (size_t)split * M * g.Co;
 #pragma unroll
@@ -442,21 +466,48 @@ __device__ __forceinline__ void igemm_tile(
 template <int BM, int BN, bool B_DGRAD, int BKT, bool UNI, int MMA = 0, int PF = 1, bool BUF = false>
 __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(
     const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ bias,
-    const float* __restrict__ addend, float* __restrict__ out, ConvShape g, int relu)
+    const float* __restrict__ addend, float* __restrict__ out, ConvShape g, int relu, float* __restrict__ stats)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    igemm_tile<BM, BN, B_DGRAD, BKT, UNI, false, MMA, PF, BUF>(X, W, bias, addend, out, g, relu, lds, blockIdx.x, gridDim.x, blockIdx.z);
+    igemm_tile<BM, BN, B_DGRAD, BKT, UNI, false, MMA, PF, BUF>(X, W, bias, addend, out, g, relu, lds, blockIdx.x, gridDim.x, blockIdx.z,
+                                                               nullptr, stats);
 }
 
 // out[i] = sum_z part[z][i] (+bias[i % ncols]) (relu)
 // Every operand of an output element is fetched before the first add (the first eight partial sums branch-free - a
 // split index past the end re-reads the last one - plus bias, addend and the old value): one memory latency per launch
 // instead of one per split.  The additions keep their order (z ascending, then bias, addend, relu, old value).
+// stats (optional; ncols a power of two <= 1024, no bias / relu): workgroup b also writes the per-column (sum, sum of squares)
+// of its 1024 / ncols rows into stats[b][2 * ncols] - BatchNorm's statistics pass folded into the reduce.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ out,
                                                             const float* __restrict__ bias, const float* __restrict__ addend,
-                                                            long total4, int ncols, int splits, int relu, int accumulate)
+                                                            long total4, int ncols, int splits, int relu, int accumulate,
+                                                            float* __restrict__ stats)
 {
+    __shared__ f32x4 red_s[2][256];
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (stats != nullptr) {                               // (every thread reaches the barrier below)
+        const bool ok = i < total4;
+        f32x4 s{0.f, 0.f, 0.f, 0.f};
+        if (ok) {
+            const f32x4* p = reinterpret_cast<const f32x4*>(part) + i;
+            s = p[0];
+            for (int z = 1; z < splits; ++z) s += p[(long)z * total4];
+            reinterpret_cast<f32x4*>(out)[i] = s;
+        }
+        red_s[0][threadIdx.x] = s;
+        red_s[1][threadIdx.x] = s * s;
+        __syncthreads();
+        const int c4 = ncols >> 2;                        // float4 columns; rows per workgroup = 256 / c4
+        if ((int)threadIdx.x < c4) {
+            f32x4 a = red_s[0][threadIdx.x], b = red_s[1][threadIdx.x];
+            for (int r = c4; r < 256; r += c4) { a += red_s[0][r + threadIdx.x]; b += red_s[1][r + threadIdx.x]; }
+            float* q = stats + (size_t)blockIdx.x * 2 * ncols + threadIdx.x * 4;
+            *reinterpret_cast<f32x4*>(q) = a;
+            *reinterpret_cast<f32x4*>(q + ncols) = b;
+        }
+        return;
+    }
     if (i >= total4) return;
     const f32x4* p = reinterpret_cast<const f32x4*>(part) + i;
     const f32x4 zero{0.f, 0.f, 0.f, 0.f};
@@ -948,7 +999,7 @@ TileChoice pick_tile(long M, long N)
     // Measured on MI355X (tests/tools/bench_conv.py): the problems of this path are small (a 5-frame clip), so what
     // matters is the number of co-resident workgroups per CU, not the tile's arithmetic intensity: 64x64 tiles with
     // the block count topped up to ~1250 by split-K beat the larger tiles on every trunk layer (72-80 us vs 85-130 us).
-    if (g_mma_mode == 3 && M <= 1216) return {64, 64};          // few-rows GEMMs run K tile 64: 110 KB of LDS with 64x64 tiles
+    if (g_mma_mode == 3 && M <= 2048) return {64, 64};          // (64x64 is the fastest tile up to the 1200 rows of a batched clip)
     if (g_mma_mode >= 1) {
         // split-bf16: the loop is bound by the operand split (VALU) and the LDS reads per MFMA, both of which shrink with
         // the wave tile - problems with enough tiles take the larger ones (bench_conv.py --mma --clips 8: 128x128 is
@@ -965,7 +1016,9 @@ struct ConvPlan { int bm, bn, splits; long tiles; };
 // (the MFMA work per barrier is 5x shorter there; measured 44-54 us vs 51-58 us on the trunk layers)
 int k_tile_for(long M, int K, int ci, int bm, int bn)
 {
-    if (M <= 1216 && K >= 64) return (g_mma_mode == 3 && g_deep_kt3 == 32) ? 32 : 64;    // (up to 5 x 240 rows: the lane head; not layer4's 1250 pixels)
+    // few-rows GEMMs (one frame of the lane head: 240 rows): deep K tiles.  With the frames of a clip batched (1200 rows) the
+    // trunk plan wins in the staged-split arithmetic: 1024 -> 8192 174 vs 260 us, 4608 -> 1024 96 vs 146 us (bench_conv --only clipB)
+    if (M <= (g_mma_mode == 3 ? 256 : 2048) && K >= 64) return (g_mma_mode == 3 && g_deep_kt3 == 32) ? 32 : 64;
     if (g_mma_mode == 3) return BK;                                   // 37 KB of LDS per 64x64 workgroup: four per CU
     if (g_mma_mode >= 1 && bm == 64 && bn == 64 && ci % 32 == 0) return 32;
     return BK;
@@ -994,7 +1047,7 @@ ConvPlan plan_conv(long M, int Co, int K, bool has_ws, size_t ws_bytes)
     // split K until ~1250 workgroups are in flight (about 5 per CU), keeping >= 256 of K per split
     // K-tile-64 plans (M <= 2048: the head GEMMs) hold 70 KB of LDS per workgroup = 2 workgroups per CU, so ~512 tiles already
     // fill the chip in one round and a split only adds the reduce pass (hyper-net 1024 -> 8192 at 240 rows: 54 vs 62 us)
-    const bool deep = M <= 1216 && K >= 64;
+    const bool deep = M <= (g_mma_mode == 3 ? 256 : 2048) && K >= 64;
     if (has_ws && p.tiles < (deep ? 400 : 900)) {
         int splits = (int)min((long)8, max((long)1, (1250 + p.tiles / 2) / p.tiles));
         while (splits > 1 && K / splits < 256) --splits;
@@ -1006,7 +1059,7 @@ ConvPlan plan_conv(long M, int Co, int K, bool has_ws, size_t ws_bytes)
 
 template <bool DGRAD>
 int launch_conv(const float* X, const float* W, const float* bias, const float* addend, float* out, float* workspace,
-                size_t ws_bytes, ConvShape g, int relu, hipStream_t st)
+                size_t ws_bytes, ConvShape g, int relu, hipStream_t st, float* stats = nullptr)
 {
     const long M = (long)g.N * g.Ho * g.Wo;
     const int K = g.R * g.S * g.Ci;
@@ -1039,7 +1092,7 @@ int launch_conv(const float* X, const float* W, const float* bias, const float* 
             attr_set_ = true;                                                                                           \
         }                                                                                                               \
         hipLaunchKernelGGL((conv_igemm_kernel<BM_, BN_, DGRAD, BKT_, UNI_, MMA_, PF_, BUF_>), grid, dim3(THREADS), lds_, st, \
-                           X, W, bias, addend, dst, g, relu);                                                           \
+                           X, W, bias, addend, dst, g, relu, splits > 1 ? (float*)nullptr : stats);                     \
     } while (0)
 #define PHNET_LAUNCH_CONV__(BM_, BN_, BKT_, UNI_, MMA_) PHNET_LAUNCH_CONV___(BM_, BN_, BKT_, UNI_, MMA_, 1)
 #define PHNET_LAUNCH_CONV_(BM_, BN_, BKT_, UNI_)                                                                        \
@@ -1073,7 +1126,7 @@ int launch_conv(const float* X, const float* W, const float* bias, const float* 
     if (splits > 1) {
         const long total4 = M * g.Co / 4;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)ceil_div64(total4, 256)), dim3(256), 0, st,
-                           workspace, out, bias, addend, total4, g.Co, splits, relu, 0);
+                           workspace, out, bias, addend, total4, g.Co, splits, relu, 0, stats);
     }
     return phnet_launch_status();
 }
@@ -1156,6 +1209,41 @@ PHNET_API int phnet_conv2d_fwd(const float* x, const float* w, const float* bias
     if (g.Ho < 1 || g.Wo < 1) return PHNET_ERR_ARG;
     g.stride = stride; g.pad = pad; g.in_dil = 1;
     return launch_conv<false>(x, w, bias, nullptr, y, (float*)workspace, ws_bytes, g, relu, (hipStream_t)stream);
+}
+
+// Forward convolution with a fused epilogue: y = conv(x, w) + bias + addend, then ReLU (each part optional; addend shaped
+// like y - the residual branch of a folded BatchNorm block in eval mode), and / or the per-channel batch statistics of y
+// for a following BatchNorm: stats = phnet_conv2d_stats_blocks() rows of 2*Co floats (sum | sum of squares), the `partial`
+// layout phnet_bn_finalize_partials reads.  stats needs bias == addend == NULL, relu == 0 and Co a power of two <= 1024.
+static long conv_stats_blocks(long M, int Co, int K, bool has_ws, size_t ws_bytes)
+{
+    const ConvPlan t = plan_conv(M, Co, K, has_ws, ws_bytes);
+    return t.splits > 1 ? ceil_div64(M * Co / 4, 256) : t.tiles / ceil_div64(Co, t.bn) * (t.bm / 32);
+}
+
+PHNET_API uint64_t phnet_conv2d_stats_blocks(int64_t M, int32_t Co, int32_t K, uint64_t ws_bytes)
+{
+    if (M < 1 || Co < 4 || K < 1) return 0;
+    return (uint64_t)conv_stats_blocks((long)M, Co, K, ws_bytes > 0, (size_t)ws_bytes);
+}
+
+PHNET_API int phnet_conv2d_fwd_fused(const float* x, const float* w, const float* bias, const float* addend, float* y, float* stats,
+                                     int32_t N, int32_t Hi, int32_t Wi, int32_t Ci, int32_t Co, int32_t R, int32_t S,
+                                     int32_t stride, int32_t pad, int32_t relu,
+                                     void* workspace, uint64_t ws_bytes, void* stream)
+{
+    if (N < 0 || Hi < 1 || Wi < 1 || Ci < 4 || Co < 4 || (Ci & 3) || (Co & 3) || R < 1 || S < 1 || stride < 1 || pad < 0)
+        return PHNET_ERR_ARG;
+    if (stats && (bias || addend || relu || (Co & (Co - 1)) || Co > 1024)) return PHNET_ERR_ARG;
+    if (N == 0) return PHNET_OK;
+    if (!x || !w || !y) return PHNET_ERR_ARG;
+    ConvShape g{};
+    g.N = N; g.Hi = Hi; g.Wi = Wi; g.Ci = Ci; g.Co = Co; g.R = R; g.S = S;
+    g.Ho = (Hi + 2 * pad - R) / stride + 1;
+    g.Wo = (Wi + 2 * pad - S) / stride + 1;
+    if (g.Ho < 1 || g.Wo < 1) return PHNET_ERR_ARG;
+    g.stride = stride; g.pad = pad; g.in_dil = 1;
+    return launch_conv<false>(x, w, bias, addend, y, (float*)workspace, ws_bytes, g, relu, (hipStream_t)stream, stats);
 }
 
 // Data gradient.  dy NHWC [N][Ho][Wo][Co], w OHWI [Co][R][S][Ci] (as used by the forward), dx NHWC [N][Hi][Wi][Ci].

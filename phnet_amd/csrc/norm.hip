@@ -416,6 +416,18 @@ PHNET_API int phnet_bn_fwd_stats(const float* x, int64_t M, int32_t C, float eps
     return phnet_launch_status();
 }
 
+// Batch statistics from per-block (sum, sum of squares) partials that the convolution's epilogue (or its split-K reduce)
+// wrote: phnet_conv2d_fwd_fused(..., stats = partial).  Same finalize kernel, no pass over x.
+PHNET_API int phnet_bn_finalize_partials(const float* partial, int64_t nblk, int64_t M, int32_t C, float eps, float momentum,
+                                         const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                         float* save_mean, float* save_invstd, float* scale, float* shift, void* stream)
+{
+    if (M < 1 || nblk < 1 || nblk > 0x7fffffff || !channels_ok(C) || !partial || !gamma || !beta || !scale || !shift) return PHNET_ERR_ARG;
+    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 3) / 4), dim3(NT), 0, (hipStream_t)stream, partial, (int)nblk, (long)M, C, eps,
+                       momentum, gamma, beta, running_mean, running_var, save_mean, save_invstd, scale, shift, 1);
+    return phnet_launch_status();
+}
+
 // y = x*scale + shift (+residual) (relu);  y may alias x.
 PHNET_API int phnet_bn_apply(const float* x, const float* scale, const float* shift, const float* residual, float* y,
                              int64_t M, int32_t C, int32_t relu, void* stream)

@@ -132,8 +132,12 @@ def conv_out_hw(hi, wi, r, s, stride, pad):
     return (hi + 2 * pad - r) // stride + 1, (wi + 2 * pad - s) // stride + 1
 
 
-def conv2d_fwd(x, w, bias, stride: int, pad: int, relu: bool = False, out: Optional[torch.Tensor] = None):
-    """x NHWC [N,Hi,Wi,Ci]; w OHWI [Co,R,S,Ci]; -> NHWC [N,Ho,Wo,Co]."""
+def conv2d_fwd(x, w, bias, stride: int, pad: int, relu: bool = False, out: Optional[torch.Tensor] = None,
+               addend: Optional[torch.Tensor] = None, stats: bool = False):
+    """x NHWC [N,Hi,Wi,Ci]; w OHWI [Co,R,S,Ci]; -> NHWC [N,Ho,Wo,Co].
+    addend (shaped like the output): y = relu?(conv + bias + addend) in the kernel's epilogue.
+    stats=True: also returns (partial, nblk) - per-channel (sum | sum of squares) partials of y written by the epilogue, for
+    bn_fwd(..., partials=...): no separate statistics pass over y."""
     _req(x, name="x"); _req(w, name="w")
     n, hi, wi, ci = x.shape
     co, r, s, ci2 = w.shape
@@ -146,6 +150,19 @@ def conv2d_fwd(x, w, bias, stride: int, pad: int, relu: bool = False, out: Optio
     need = 8 * n * ho * wo * co * 4 if n * ho * wo * co < (1 << 23) else 0
     ws = workspace(need, x.device) if need else None
     m, k = n * ho * wo, r * s * ci
+    if addend is not None or stats:
+        part, nblk = None, 0
+        if stats:
+            nblk = int(lib().phnet_conv2d_stats_blocks(m, co, k, need))
+            part = workspace(nblk * 2 * co * 4, x.device, 1)
+        if addend is not None:
+            _req(addend, name="addend")
+            assert addend.shape == out.shape
+        _timed_launch(lambda: _gemm_symbol(m, co, k, need, False, ci), 2.0 * m * co * k,
+                      lambda: check(lib().phnet_conv2d_fwd_fused(_ptr(x), _ptr(w), _ptr(bias), _ptr(addend), _ptr(out), _ptr(part), n, hi, wi,
+                                                                 ci, co, r, s, stride, pad, int(relu), _ptr(ws), need, _stream()),
+                                    "phnet_conv2d_fwd_fused"))
+        return (out, (part, nblk)) if stats else out
     _timed_launch(lambda: _gemm_symbol(m, co, k, need, False, ci), 2.0 * m * co * k,
                   lambda: check(lib().phnet_conv2d_fwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(out), n, hi, wi, ci, co, r, s, stride,
                                                        pad, int(relu), _ptr(ws), need, _stream()), "phnet_conv2d_fwd"))
@@ -252,8 +269,9 @@ def _partials(m, c, device, slot=1):
 
 
 def bn_fwd(x, gamma, beta, running_mean, running_var, training: bool, eps: float, momentum: float,
-           residual=None, relu: bool = True):
-    """x [..., C] NHWC conv output.  Returns (y, save_mean, save_invstd); stats tensors are None in eval."""
+           residual=None, relu: bool = True, partials=None):
+    """x [..., C] NHWC conv output.  Returns (y, save_mean, save_invstd); stats tensors are None in eval.
+    partials = (partial, nblk) from conv2d_fwd(..., stats=True): the batch statistics come from the convolution's epilogue."""
     _req(x, name="x")
     c = x.shape[-1]
     m = x.numel() // c
@@ -262,10 +280,15 @@ def bn_fwd(x, gamma, beta, running_mean, running_var, training: bool, eps: float
     shift = torch.empty(c, dtype=torch.float32, device=dev)
     sm = torch.empty(c, dtype=torch.float32, device=dev) if training else None
     si = torch.empty(c, dtype=torch.float32, device=dev) if training else None
-    part = _partials(m, c, dev) if training else None
-    check(lib().phnet_bn_fwd_stats(_ptr(x), m, c, eps, momentum, _ptr(gamma), _ptr(beta), _ptr(running_mean),
-                                   _ptr(running_var), _ptr(sm), _ptr(si), _ptr(scale), _ptr(shift), _ptr(part),
-                                   int(training), _stream()), "phnet_bn_fwd_stats")
+    if training and partials is not None:
+        check(lib().phnet_bn_finalize_partials(_ptr(partials[0]), int(partials[1]), m, c, eps, momentum, _ptr(gamma), _ptr(beta),
+                                               _ptr(running_mean), _ptr(running_var), _ptr(sm), _ptr(si), _ptr(scale), _ptr(shift),
+                                               _stream()), "phnet_bn_finalize_partials")
+    else:
+        part = _partials(m, c, dev) if training else None
+        check(lib().phnet_bn_fwd_stats(_ptr(x), m, c, eps, momentum, _ptr(gamma), _ptr(beta), _ptr(running_mean),
+                                       _ptr(running_var), _ptr(sm), _ptr(si), _ptr(scale), _ptr(shift), _ptr(part),
+                                       int(training), _stream()), "phnet_bn_fwd_stats")
     y = torch.empty_like(x)
     check(lib().phnet_bn_apply(_ptr(x), _ptr(scale), _ptr(shift), _ptr(residual), _ptr(y), m, c, int(relu), _stream()),
           "phnet_bn_apply")
@@ -597,16 +620,23 @@ def attention_bwd(q, k, v, o, dout, lse, heads: int, dq, dk, dv, key_valid=None,
                                     _stream()), "phnet_attention_bwd")
 
 
-def memory_tokens(feat, rows):
+def memory_tokens(feat, rows, out=None):
     """feat [N,E] / [N,1,E] with rows i64[L] (-1 padded) -> (tokens [L+1,1,E], valid bool[L+1]); or a batch of clips:
-    feat [B,N,E] with rows i64[B,L] -> (tokens [B,L+1,E], valid bool[B,L+1]).  One launch."""
+    feat [B,N,E] with rows i64[B,L] -> (tokens [B,L+1,E], valid bool[B,L+1]).  One launch.  out = (tokens, valid): write into
+    caller-provided contiguous tensors (a slot of a ring buffer) instead of allocating."""
     _req(feat, name="feat"); _req(rows, torch.int64, "rows")
     batched = rows.dim() == 2
     b = rows.shape[0] if batched else 1
     l, e = rows.shape[-1], feat.shape[-1]
     n = feat.numel() // (b * e)
-    tokens = torch.empty((b, l + 1, e) if batched else (l + 1, 1, e), dtype=torch.float32, device=feat.device)
-    valid = torch.empty((b, l + 1) if batched else (l + 1,), dtype=torch.bool, device=feat.device)
+    if out is not None:
+        tokens, valid = out
+        _req(tokens, name="tokens out")
+        if tokens.numel() != b * (l + 1) * e or valid.numel() != b * (l + 1) or valid.dtype != torch.bool or not valid.is_contiguous():
+            raise ValueError("memory_tokens: out buffers do not match (tokens [..,L+1,E] f32, valid [..,L+1] bool, contiguous)")
+    else:
+        tokens = torch.empty((b, l + 1, e) if batched else (l + 1, 1, e), dtype=torch.float32, device=feat.device)
+        valid = torch.empty((b, l + 1) if batched else (l + 1,), dtype=torch.bool, device=feat.device)
     check(lib().phnet_memory_tokens(_ptr(feat), _ptr(rows), _ptr(tokens), _ptr(valid), b, n, e, l, _stream()), "phnet_memory_tokens")
     return tokens, valid
 

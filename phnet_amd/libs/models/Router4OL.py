@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 
 from phnet_amd import functional as PF
-from phnet_amd.arena import grad_sink
+from phnet_amd.arena import SinkPool, grad_sink
 from phnet_amd.trunk import encoder_forward
 from ..ops import nms
 from ..utils.lane import Lane
@@ -104,6 +104,7 @@ class DetNetV2(nn.Module):
         self.router = AdaptiveRouter4Lane(num_priors=self.num_priors, features_channels=prior_feat_channels,
                                           num_points=sample_points, out_channels=1, reduction=4, stages=refine_layers)
         self._branch_cache = None              # per-clip cache of the assembled tower weights (see _branch_weights)
+        self._sink_pool = None                 # per-clip zero buffers of the gradient sinks (phnet_amd.arena.SinkPool)
 
     # ---- anchors ---------------------------------------------------------------------------------------------
     def _initial_anchors(self) -> torch.Tensor:
@@ -161,7 +162,7 @@ class DetNetV2(nn.Module):
             if pad:
                 wh = torch.cat([wh, wh.new_zeros(pad, wh.shape[1])], dim=0)
                 bh = torch.cat([bh, bh.new_zeros(pad)], dim=0)
-            self._branch_cache[key] = tuple(grad_sink(t) for t in (w1, b1, w2, b2, wh, bh))
+            self._branch_cache[key] = tuple(grad_sink(t, self._sink_pool) for t in (w1, b1, w2, b2, wh, bh))
         return self._branch_cache[key]
 
     def _branch(self, feat, priors, sec: bool):
@@ -198,8 +199,10 @@ class DetNetV2(nn.Module):
     def stage_back(self, front, stage, priors, memory):
         """Branch B of ONE frame on top of its stage_front results (all [1,...])."""
         gate, local = front["gate"], front["local"]
-        pos = self.PositionEmbedding.embed.weight.unsqueeze(1)                       # [N,1,C]
-        attn = torch.cat([local.transpose(0, 1), pos], dim=-1)                       # [N,1,2C]
+        attn = front.get("attn")
+        if attn is None:
+            pos = self.PositionEmbedding.embed.weight.unsqueeze(1)                   # [N,1,C]
+            attn = torch.cat([local.transpose(0, 1), pos], dim=-1)                   # [N,1,2C]
         pred_b, lines_b = self.forward_second(memory, attn, stage, priors)
         return dict(pred_a=front["pred_a"], lines_a=front["lines_a"], pred_b=pred_b, lines_b=lines_b, attn=attn, gate=gate, local=local)
 
@@ -355,8 +358,9 @@ class RouterOL(nn.Module):
     def _begin_clip(self):
         det = self.detNet
         det._branch_cache = None                                               # weights may have changed since the last clip
+        det._sink_pool = SinkPool() if self.training else None
         for head in det.DHead_series:
-            head.begin_clip()
+            head.begin_clip(det._sink_pool)
         # the anchors expanded from the embeddings are kept on the module (as in the reference, Router4OL.py:258-259) - but
         # without their autograd history: a graph that outlives its step keeps AccumulateGrad nodes bound to that step's
         # stream, and a later hipGraph capture on another stream then faults (PyTorch: "AccumulateGrad node's stream does
@@ -476,18 +480,24 @@ class RouterOL(nn.Module):
         per_frame = [{"predictions_fir": [], "predictions_sec": [], "gates": []} for _ in range(T)]
         for stage in range(det.refine_layers):
             front = det.stage_front(levels[stage], stage, priors, on_map, pro)                 # everything [T,...]
+            # branch B's input (content | learned position) of all frames in one cat; per-frame views of it below
+            front["attn"] = torch.cat([front["local"], det.PositionEmbedding.embed.weight.unsqueeze(0).expand(T, -1, -1)], dim=-1)
             parts = {k: v.split(1, dim=0) for k, v in front.items()}                          # one cat in the backward
             pri_t = priors.split(1, dim=0) if priors.requires_grad else [priors[t:t + 1] for t in range(T)]
-            tokens, lines_b = [], []
+            # memory tokens of this stage: frame t's slot of one ring buffer, the attention window is a contiguous slice
+            L1 = lanes.shape[1] + 1
+            ring = torch.empty((T, L1, 1, front["attn"].shape[-1]), dtype=torch.float32, device=frame.device)
+            ring_valid = torch.empty((T, L1), dtype=torch.bool, device=frame.device)
+            lines_b = []
             for t in range(T):
-                window = tokens[max(0, t - self.save_freq_max):t]
-                mem = None
-                if window:
-                    mem = (torch.cat([w[0] for w in window], dim=0), torch.cat([w[1] for w in window], dim=0))
-                r = det.stage_back({k: parts[k][t] for k in parts}, stage, pri_t[t], mem)
+                t0 = max(0, t - self.save_freq_max)
+                mem = (ring[t0:t].view(-1, 1, ring.shape[-1]), ring_valid[t0:t].view(-1)) if t > 0 else None
+                fr = {k: parts[k][t] for k in parts}
+                fr["attn"] = fr["attn"].transpose(0, 1)                                       # [N,1,2C] view
+                r = det.stage_back(fr, stage, pri_t[t], mem)
                 with torch.no_grad():
                     _, rows_sorted, _ = K.lane_assign(r["pred_b"][0].detach().contiguous(), lanes[t].contiguous(), det.img_w, det.img_h)
-                    tokens.append(self._tokens(r["attn"].detach(), rows_sorted))
+                    K.memory_tokens(r["attn"].detach().contiguous(), rows_sorted.contiguous(), out=(ring[t], ring_valid[t]))
                 per_frame[t]["predictions_fir"].append(r["pred_a"])
                 per_frame[t]["predictions_sec"].append(r["pred_b"])
                 per_frame[t]["gates"].append(r["gate"])

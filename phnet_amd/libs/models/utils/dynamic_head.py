@@ -22,9 +22,11 @@ class DynamicConv(nn.Module):
         self.out_layer = nn.Sequential(nn.Linear(c * feat_size, 6 * c), nn.Linear(6 * c, c))
         self.norm3 = nn.LayerNorm(c)
         self._folded = None          # per-clip cache of folded Linear->Linear pairs (see _fold)
+        self._sink_pool = None
 
-    def begin_clip(self):
+    def begin_clip(self, sink_pool=None):
         self._folded = None
+        self._sink_pool = sink_pool
 
     def _fold(self, name: str, seq: nn.Sequential):
         """A Linear->Linear pair with nothing in between (dynamic_head.py:16-17, 27-28) is one affine map:
@@ -38,7 +40,7 @@ class DynamicConv(nn.Module):
             l1, l2 = seq[0], seq[1]
             w_eff_t = PF.linear(l1.weight.t().contiguous(), l2.weight)              # [K, N] = (W2 W1)^T
             b_eff = PF.linear(l1.bias.unsqueeze(0), l2.weight, l2.bias)[0]          # W2 b1 + b2
-            self._folded[name] = (grad_sink(w_eff_t.t().contiguous()), grad_sink(b_eff.contiguous()))
+            self._folded[name] = (grad_sink(w_eff_t.t().contiguous(), self._sink_pool), grad_sink(b_eff.contiguous(), self._sink_pool))
         return self._folded[name]
 
     def forward(self, pro_feature: torch.Tensor, roi_feature: torch.Tensor) -> torch.Tensor:

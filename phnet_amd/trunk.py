@@ -57,19 +57,51 @@ def _conv_bn(tape: list, x, conv: nn.Conv2d, bn, training: bool, relu: bool, res
     rec.stride, rec.pad = conv.stride[0], conv.padding[0]
     rec.w = w_override if w_override is not None else ohwi(conv.weight)
     rec.x_in = x
-    rec.c = K.conv2d_fwd(x, rec.w, None, rec.stride, rec.pad)
     mom = bn.momentum if bn.momentum is not None else 0.1
     rec.sync_count = None
-    if training and _sync_bn(bn):
+    rec.relu, rec.has_res = relu, residual is not None
+    if not training and bn.running_mean is not None:
+        # eval: scale / shift of the running statistics folded into the weights and a bias (cached until a parameter or a
+        # statistic changes), residual add and ReLU in the GEMM epilogue - ONE launch per conv/BN/ReLU block, no
+        # elementwise pass (resnet.py:79-95 in eval mode: y = relu(bn(conv(x)) + identity))
+        wf, bf = _folded(conv, bn, rec.w)
+        rec.c = rec.y = K.conv2d_fwd(x, wf, bf, rec.stride, rec.pad, relu=relu, addend=residual)
+        rec.sm = rec.si = None
+    elif training and _sync_bn(bn):
+        rec.c = K.conv2d_fwd(x, rec.w, None, rec.stride, rec.pad)
         rec.y, rec.sm, rec.si, rec.sync_count = K.bn_fwd_sync(rec.c, bn.weight.detach(), bn.bias.detach(), bn.running_mean,
                                                               bn.running_var, bn.eps, mom, residual, relu,
                                                               getattr(bn, "process_group", None))
     else:
+        # training: the batch statistics come out of the convolution's own epilogue (per-slab partial sums), no second pass
+        co = rec.w.shape[0]
+        fused_stats = training and co <= 1024 and (co & (co - 1)) == 0
+        if fused_stats:
+            rec.c, partials = K.conv2d_fwd(x, rec.w, None, rec.stride, rec.pad, stats=True)
+        else:
+            rec.c, partials = K.conv2d_fwd(x, rec.w, None, rec.stride, rec.pad), None
         rec.y, rec.sm, rec.si = K.bn_fwd(rec.c, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
-                                         training, bn.eps, mom, residual, relu)
-    rec.relu, rec.has_res = relu, residual is not None
+                                         training, bn.eps, mom, residual, relu, partials=partials)
     tape.append(rec)
     return rec.y
+
+
+_FOLD_CACHE = {}
+
+
+def _folded(conv: nn.Conv2d, bn, w_ohwi: torch.Tensor):
+    """(w * gamma / sqrt(var + eps) per output channel, beta - mean * gamma / sqrt(var + eps)) for an eval-mode conv -> BN pair."""
+    ver = (conv.weight._version, bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version,
+           conv.weight.data_ptr(), bn.running_mean.data_ptr(), w_ohwi.shape)
+    hit = _FOLD_CACHE.get(id(bn))
+    if hit is not None and hit[0] == ver:
+        return hit[1], hit[2]
+    with torch.no_grad():
+        scale = bn.weight.detach() * torch.rsqrt(bn.running_var + bn.eps)
+        wf = (w_ohwi.reshape(w_ohwi.shape[0], -1) * scale[:, None]).reshape(w_ohwi.shape).contiguous()
+        bf = (bn.bias.detach() - bn.running_mean * scale).contiguous()
+    _FOLD_CACHE[id(bn)] = (ver, wf, bf)
+    return wf, bf
 
 
 class _Tape:

@@ -209,12 +209,20 @@ def gpu_ddp_syncbn_wrap(rank, world):
     ld = ddp({"frame": frames, "lanes": lanes})
     ld.backward()
     torch.cuda.synchronize()
-    worst = 0.0
+    worst, worst_gate, names = 0.0, 0.0, []
     for (k, a), (_, b) in zip(ref.named_parameters(), model.named_parameters()):
         assert b.grad is not None, k
-        worst = max(worst, float((a.grad - b.grad).abs().max() / (a.grad.abs().max() + 1e-6)))
+        if ".DWNets." in k and k.endswith((".0.bias", ".3.bias")):
+            continue        # depth-wise conv bias in front of a LayerNorm over the whole plane: true gradient 0, fp32 noise only
+        e = float((a.grad - b.grad).abs().max() / (a.grad.abs().max() + 1e-6))
+        names.append((round(e, 5), k))
+        if k.startswith("detNet.router."):
+            worst_gate = max(worst_gate, e)        # (one anchor at the gate's ReLU threshold may flip between the two runs)
+        else:
+            worst = max(worst, e)
+    print("worst gradient mismatches:", sorted(names)[-6:], flush=True)
     rm = float((ref.backbone.backbone.model.bn1.running_var - model.backbone.backbone.model.bn1.running_var).abs().max())
-    return {"loss_ref": float(lr), "loss_ddp": float(ld), "worst_grad_rel": worst, "running_var_err": rm}
+    return {"loss_ref": float(lr), "loss_ddp": float(ld), "worst_grad_rel": worst, "worst_gate_grad_rel": worst_gate, "running_var_err": rm}
 
 
 def gpu_rccl_inside_capture(rank, world):

@@ -357,6 +357,46 @@ def test_batchnorm_train_fwd_bwd(ops, shape, relu, res):
         close(dres, r.grad.permute(0, 2, 3, 1), 1e-6)
 
 
+@pytest.mark.parametrize("case", [(5, 20, 50, 64, 64, 3, 1, 1), (1, 10, 25, 512, 512, 3, 1, 1), (5, 20, 50, 64, 128, 3, 2, 1),
+                                  (2, 33, 47, 4, 64, 7, 2, 3), (1, 80, 200, 64, 64, 3, 1, 1), (3, 9, 13, 128, 256, 1, 1, 0)])
+@pytest.mark.parametrize("mode", ["bf16x3", "f32"])
+def test_conv_epilogue_statistics_feed_batchnorm(ops, case, mode):
+    """phnet_conv2d_fwd_fused(stats): the per-channel (sum, sum of squares) partials written by the GEMM epilogue - or by the
+    split-K reduce when the plan splits K - finalised by phnet_bn_finalize_partials give the same BatchNorm forward (output,
+    saved mean / invstd, running statistics) as the separate statistics pass; and the fused residual + ReLU epilogue
+    (eval-mode BatchNorm folded into weights and bias) equals conv -> affine -> add -> relu."""
+    N, Hi, Wi, Ci, Co, R, stride, pad = case
+    torch.manual_seed(sum(case))
+    ops.set_mma_mode(mode)
+    try:
+        x = torch.randn(N, Hi, Wi, Ci, device="cuda")
+        w = torch.randn(Co, R, R, Ci, device="cuda") / (Ci * R * R) ** 0.5
+        g, b = torch.rand(Co, device="cuda") + 0.5, torch.randn(Co, device="cuda")
+        c0 = ops.conv2d_fwd(x, w, None, stride, pad)
+        c1, partials = ops.conv2d_fwd(x, w, None, stride, pad, stats=True)
+        assert torch.equal(c0, c1)
+        part, nblk = partials
+        sums = part.view(torch.float32)[: nblk * 2 * Co].view(nblk, 2, Co).double().sum(0)
+        flat = c0.reshape(-1, Co).double()
+        close(sums[0], flat.sum(0), 1e-5); close(sums[1], (flat * flat).sum(0), 1e-5)
+        rm0, rv0 = torch.zeros(Co, device="cuda"), torch.ones(Co, device="cuda")
+        rm1, rv1 = rm0.clone(), rv0.clone()
+        res = torch.randn_like(c0)
+        # (the fused partials first: the separate statistics pass reuses the same scratch slot)
+        y1, sm1, si1 = ops.bn_fwd(c1, g, b, rm1, rv1, True, 1e-5, 0.1, res, True, partials=partials)
+        y0, sm0, si0 = ops.bn_fwd(c0, g, b, rm0, rv0, True, 1e-5, 0.1, res, True)
+        close(y1, y0, 1e-5); close(sm1, sm0, 1e-6); close(si1, si0, 1e-5); close(rm1, rm0, 1e-6); close(rv1, rv0, 1e-5)
+        # eval fold: relu(conv(x, w * s) + (beta - mean * s) + res) in ONE launch
+        mean, var = torch.randn(Co, device="cuda") * 0.1, torch.rand(Co, device="cuda") + 0.5
+        sc = g * torch.rsqrt(var + 1e-5)
+        fused = ops.conv2d_fwd(x, (w.reshape(Co, -1) * sc[:, None]).reshape(w.shape).contiguous(), (b - mean * sc).contiguous(),
+                               stride, pad, relu=True, addend=res)
+        want = torch.relu((c0.double() - mean.double()) * sc.double() + b.double() + res.double())
+        close(fused, want, 2e-5)
+    finally:
+        ops.set_mma_mode(ops.DEFAULT_MMA)
+
+
 def test_batchnorm_eval(ops):
     x = torch.randn(2, 64, 8, 10, dtype=torch.float64)
     g, b = torch.rand(64, dtype=torch.float64) + 0.5, torch.randn(64, dtype=torch.float64)

@@ -20,6 +20,12 @@ SHAPES = [  # name, N,Hi,Wi,Ci,Co,R,stride,pad
     ("out 2304->384", 240, 1, 1, 2304, 384, 1, 1, 0),
     ("tower 64->64", 240, 1, 1, 64, 64, 1, 1, 0),
     ("tower 128->128", 240, 1, 1, 128, 128, 1, 1, 0),
+    # the same layers with the 5 frames of a clip batched (stage-major training schedule): 1200 rows
+    ("clipB 1024->8192", 1200, 1, 1, 1024, 8192, 1, 1, 0),
+    ("clipB 4608->1024", 1200, 1, 1, 4608, 1024, 1, 1, 0),
+    ("clipB 64->8192", 1200, 1, 1, 64, 8192, 1, 1, 0),
+    ("clipB 2304->576", 1200, 1, 1, 2304, 576, 1, 1, 0),
+    ("clipB 2304->64", 1200, 1, 1, 2304, 64, 1, 1, 0),
 ]
 
 def timeit(fn, iters=20):
