@@ -149,6 +149,16 @@ int phnet_bn_bwd_apply_sums(const float* dy, const float* x, const float* y, con
                             const float* gamma, const float* sums, const double* count, float* c1, float* c2,
                             float* dx, float* dres, int64_t M, int32_t C, int32_t relu, int32_t dres_accumulate, void* stream);
 
+/* ---- input pre-processing of a clip: libs/dataset/openlane/datasetOL.py:40-52 (crop top rows, optional
+ * flip), transforms.py:150-156 (iaa.Resize = cv2 INTER_CUBIC on uint8), datasetOL.py:63-75,11-17 (ToTensor, Normalize, stack).
+ * frames u8 [T][H0][W0][3] RGB on the device; out f32 NCHW [T][3][oh][ow] (layout 0) or NHWC4 [T][oh][ow][4] (layout 1);
+ * out_u8 optional [T][oh][ow][3]; xi/xc [ow][4], yi/yc [oh][4]: clamped source indices (int32) and 11-bit taps (int16, sum 2048)
+ * of the half-pixel a = -0.75 cubic kernel, built once per geometry by the caller; mean3 / std3 are HOST pointers. ---- */
+int phnet_preprocess_u8(const uint8_t* frames, float* out, uint8_t* out_u8,
+                        const int32_t* xi, const int16_t* xc, const int32_t* yi, const int16_t* yc,
+                        int32_t T, int32_t H0, int32_t W0, int32_t crop_top, int32_t out_h, int32_t out_w, int32_t flip,
+                        int32_t layout, const float* mean3_host, const float* std3_host, void* stream);
+
 /* ---- MaxPool2d(3,2,1): libs/models/resnet.py:217,297 ---- */
 int phnet_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* argmax, int32_t N, int32_t Hi, int32_t Wi, int32_t C, void* stream);
 int phnet_maxpool3x3s2_bwd(const float* dy, const uint8_t* argmax, float* dx, int32_t N, int32_t Hi, int32_t Wi, int32_t C, void* stream);
