@@ -495,18 +495,20 @@ def test_dropout_masks_advance_with_each_graph_replay_and_match_between_forward_
         assert float(loss_with_pinned_masks(snap + 8)) != float(loss_with_pinned_masks(snap))
 
 
-def test_stage_major_training_schedule_equals_frame_major():
-    """RouterOL.stage_major (every stage's frame-independent part batched over the clip's frames, branch B + assignment +
-    memory tokens walking the frames) against the reference-shaped frame-major loop: same per-frame losses and matched
-    anchors (the stand-alone assignment that feeds the memory == the criterion's own), gradients to re-association noise.
-    11 frames: three more than the memory depth, so the token window slides."""
+@pytest.mark.parametrize("schedule", ["stage", "wavefront"])
+def test_batched_training_schedules_equal_frame_major(schedule):
+    """RouterOL.schedule: "stage" (every stage's frame-independent part batched over the clip's frames, branch B + assignment
+    + memory tokens walking the frames) and "wavefront" (the pairs of an anti-diagonal t + s = d share ONE batched branch-B
+    pass, memory windows as masked fixed-length ring slices) against the reference-shaped frame-major loop: same per-frame
+    losses and matched anchors (the stand-alone assignment that feeds the memory == the criterion's own), gradients to
+    re-association noise.  11 frames: three more than the memory depth, so the token window slides."""
     g = O.Geometry(img_h=64, img_w=160, arch="resnet18")
     T = 11
     frames, lanes = synth.make_clip(g, T, seed=13).cuda(), synth.make_targets(g, T, counts=(3, 0, 4, 1, 2, 3, 3, 2, 4, 1, 3)).cuda()
     out = []
-    for stage_major in (False, True):
+    for sched in ("frame", schedule):
         model = _build(g).train()
-        model.stage_major = stage_major
+        model.schedule = sched
         rec, undo = _record_heads(model)
         loss = model({"frame": frames, "lanes": lanes})
         loss.backward()
