@@ -14,6 +14,7 @@ import numpy as np
 import torch
 
 from oracle import phnet_cpu as O
+from oracle import phnet_cpu_v2 as O2
 
 
 def _rng(name: str, salt: int = 0):
@@ -120,7 +121,7 @@ def state_spec(g: O.Geometry) -> "OrderedDict[str, tuple]":
     return spec
 
 
-_NORM_RE = re.compile(r"(\.bn\d|downsample\.1|\.norm\d?|pre_norm\.\d|DWNets\.\d\.\d\.[14])\.(weight|bias)$")
+_NORM_RE = re.compile(r"(\.bn\d?|downsample\.1|\.norm\d?|pre_norm\.\d|DWNets\.\d\.\d\.[14])\.(weight|bias)$")
 
 
 def synth_tensor(name: str, shape: tuple, g: O.Geometry) -> torch.Tensor:
@@ -209,3 +210,117 @@ def make_targets(g: O.Geometry, T: int, n_lanes: int = 3, max_lanes_in_label: in
             out[t, j, 5] = n / g.n_strips
             out[t, j, 6:6 + n] = xs
     return torch.from_numpy(out)
+
+
+# ------------------------------------------------------------------------------------------------ Router4OLV2 family
+def state_spec_v2(g: "O2.GeometryV2") -> "OrderedDict[str, tuple]":
+    """name -> shape of libs.models.Router4OLV2.RouterOL.state_dict(), in registration order (frozen against the
+    reference in tests/golden/state_keys_v2.json by make_goldens_v2.py)."""
+    spec = OrderedDict()
+    g1 = O.Geometry(arch=g.arch)
+    for k, v in state_spec(g1).items():                     # the trunk is the V1 trunk (all four layers are registered)
+        if k.startswith("backbone.backbone."):
+            spec[k] = v
+    S, N, E = g.num_points, g.num_priors, g.hidden
+
+    def bn(prefix, c):
+        for leaf, shp in (("weight", (c,)), ("bias", (c,)), ("running_mean", (c,)), ("running_var", (c,)), ("num_batches_tracked", ())):
+            spec[f"{prefix}.{leaf}"] = shp
+
+    def lin(prefix, i, o):
+        spec[prefix + ".weight"] = (o, i)
+        spec[prefix + ".bias"] = (o,)
+
+    def ln(prefix, *shape):
+        spec[prefix + ".weight"] = tuple(shape)
+        spec[prefix + ".bias"] = tuple(shape)
+
+    p = "backbone.neck."
+    for i, (ci, co) in enumerate(zip(g.neck_in, g.neck_out)):
+        spec[f"{p}lateral_convs.{i}.conv.weight"] = (co, ci, 1, 1)
+        spec[f"{p}lateral_convs.{i}.conv.bias"] = (co,)
+    for i, co in enumerate(g.neck_out):
+        spec[f"{p}fpn_convs.{i}.conv.weight"] = (co, co, 3, 3)
+        spec[f"{p}fpn_convs.{i}.conv.bias"] = (co,)
+    for i in range(len(g.neck_out) - 1):
+        spec[f"{p}upsample_convs.{i}.conv.weight"] = (g.neck_out[i], g.neck_out[i + 1], 1, 1)
+        spec[f"{p}upsample_convs.{i}.conv.bias"] = (g.neck_out[i],)
+    d = "router."
+    for s, pnum in enumerate(g.sample_points):
+        spec[f"{d}sample_x_indexs_{s}"] = (pnum,)
+        spec[f"{d}prior_feat_ys_{s}"] = (pnum,)
+    spec[d + "prior_ys"] = (S,)
+    spec[d + "priors"] = (N, 6 + S)
+    spec[d + "priors_on_featmap"] = (N, g.sample_points[0])
+    spec[d + "prior_embeddings.weight"] = (N, 3)
+    for suffix in ("", "_sec"):
+        for kind in ("reg", "cls"):
+            for idx in (0, 2):
+                lin(f"{d}{kind}_modules{suffix}.{idx}", E, E)
+        lin(f"{d}reg_layers{suffix}", E, S + 4)
+        lin(f"{d}cls_layers{suffix}", E, 2)
+    for li in range(2):
+        q = f"{d}transformer_Dec.layers.{li}."
+        for att in ("self_attn", "multihead_attn"):
+            spec[q + att + ".in_proj_weight"] = (3 * E, E)
+            spec[q + att + ".in_proj_bias"] = (3 * E,)
+            lin(q + att + ".out_proj", E, E)
+        lin(q + "linear1", E, 512)
+        lin(q + "linear2", 512, E)
+        for k in (1, 2, 3):
+            ln(q + f"norm{k}", E)
+    ln(d + "transformer_Dec.norm", E)
+    spec[d + "PositionEmbedding.pos_table"] = (N, E)
+    for s, (c, pnum) in enumerate(zip(g.feat_channels, g.sample_points)):
+        q = f"{d}DHead_series.{s}."
+        npar = c * 2 * c
+        lin(q + "dynamic_layer_1.0", E, npar // 4)
+        lin(q + "dynamic_layer_1.1", npar // 4, npar)
+        lin(q + "dynamic_layer_2.0", 2 * c * pnum, npar // 4)
+        lin(q + "dynamic_layer_2.1", npar // 4, npar)
+        ln(q + "norm1", 2 * c)
+        ln(q + "norm2", c)
+        lin(q + "out_layer.0", c * pnum, 2 * E)
+        lin(q + "out_layer.1", 2 * E, E)
+        ln(q + "norm3", E)
+    spec[d + "pro_embedding.weight"] = (N, E)
+    r = d + "router."
+    clast = g.feat_channels[-1]
+    for s, (c, pnum) in enumerate(zip(g.feat_channels, g.sample_points)):
+        spec[f"{r}layers.{s}.0.conv.weight"] = (c // 4, c, 3)
+        bn(f"{r}layers.{s}.0.bn", c // 4)
+        spec[f"{r}layers.{s}.1.conv.weight"] = (c // clast, c // 4, 1)
+        bn(f"{r}layers.{s}.1.bn", c // clast)
+        lin(f"{r}layers.{s}.3", c * pnum // clast, pnum)
+    return spec
+
+
+_V2_BUFFERS = re.compile(r"(sample_x_indexs_\d|prior_feat_ys_\d|prior_ys|priors|priors_on_featmap|pos_table)$")
+
+
+def make_state_v2(g: "O2.GeometryV2") -> "OrderedDict[str, torch.Tensor]":
+    spec = state_spec_v2(g)
+    g1 = O.Geometry(img_h=g.img_h, img_w=g.img_w, num_points=g.num_points, num_priors=g.num_priors, arch=g.arch)
+    sd = OrderedDict()
+    for name, shape in spec.items():
+        if _V2_BUFFERS.search(name):
+            continue
+        if len(shape) == 3:                                  # Conv1d weights of the gate
+            r = _rng(name)
+            sd[name] = torch.from_numpy(r.normal(0, math.sqrt(2.0 / (shape[1] * shape[2])), shape).astype(np.float32))
+            continue
+        sd[name] = synth_tensor(name, shape, g1)
+    for suffix in ("", "_sec"):                              # rows 4.. of reg_layers are the per-row x offsets: keep them small
+        sd[f"router.reg_layers{suffix}.weight"][4:] *= 0.2
+        sd[f"router.reg_layers{suffix}.bias"][4:] *= 0.2
+    for s in range(g.refine_layers):                         # gate logits of both signs (hard routing takes both branches)
+        sd[f"router.router.layers.{s}.3.bias"] -= sd[f"router.router.layers.{s}.3.bias"].mean()
+    pri, on_map = O2.priors_from_embeddings(sd["router.prior_embeddings.weight"], g)
+    for s in range(g.refine_layers):
+        sd[f"router.sample_x_indexs_{s}"] = O2.sample_x_indexs(g, s)
+        sd[f"router.prior_feat_ys_{s}"] = O2.prior_feat_ys(g, s)
+    sd["router.prior_ys"] = O.prior_ys(g1)
+    sd["router.priors"] = pri.clone()
+    sd["router.priors_on_featmap"] = on_map.clone()
+    sd["router.PositionEmbedding.pos_table"] = O2.positional_table(g.num_priors, g.hidden)
+    return OrderedDict((k, sd[k]) for k in spec)
