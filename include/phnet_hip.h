@@ -273,6 +273,25 @@ int phnet_gate_tail_bwd(const float* dout, const float* out, const float* h, con
 int phnet_blend_priors(const float* gate, const float* a, const float* b, const int64_t* idx, float* priors, float* on_map,
                        int32_t N, int32_t W, int32_t P, void* stream);
 
+/* ---- Router4OLV2 model family (what testOLV3.py imports; inference only - its training path cannot run as shipped) ----
+ * phnet_gate_v2_fwd: AdaptiveRouter4LaneV2.forward (libs/models/Router.py:83-132) in one launch: Conv1d(k3, pad 1, no bias)
+ *   + BatchNorm1d + ReLU, Conv1d(k1) + BatchNorm1d + ReLU, Flatten, Linear(C2*P -> P), mean over the P outputs, sigmoid.
+ *   x [M][C][P]; w1 [C1][C][3]; s1 / t1 [C1] BatchNorm folded to conv * s + t; w2 [C2][C1]; s2 / t2 [C2]; wl [P][C2*P];
+ *   bl [P]; out [M].
+ * phnet_dyn_bmm_ln_relu_fwd_any: the two per-anchor products of DynamicConvV2 (libs/models/utils/dynamic_head.py:94-104) at
+ *   run-time shapes (per-level widths 64/32/16, 24/48/96 sample points), forward only: y[n] = relu(LayerNorm_J(x[n] @ w[n])).
+ * phnet_route_lines: RouterOL.forward, eval (libs/models/Router4OLV2.py:508-511): d = mean over the S stage gates, then
+ *   hard != 0: out = d >= 0.5 ? b : a (torch.where);  hard == 0: out = b * d + a * (1 - d) (Router4OL.py:538-541).
+ *   gates [S][M]; a (branch A), b (branch B), out [M][W].
+ * The per-level ROI pooling is phnet_roi_pool_fwd with C < 64, the 8 x 32 attention phnet_attention_fwd with E = 32 H. */
+int phnet_gate_v2_fwd(const float* x, const float* w1, const float* s1, const float* t1, const float* w2,
+                      const float* s2, const float* t2, const float* wl, const float* bl, float* out,
+                      int32_t M, int32_t C, int32_t P, int32_t C1, int32_t C2, void* stream);
+int phnet_dyn_bmm_ln_relu_fwd_any(const float* x, const float* w, const float* gamma, const float* beta, float* y,
+                                  int32_t N, int32_t P, int32_t K, int32_t J, float eps, void* stream);
+int phnet_route_lines(const float* gates, const float* a, const float* b, float* out,
+                      int32_t S, int32_t M, int32_t W, int32_t hard, void* stream);
+
 /* ---- optimizer: one AdamW step (torch.optim.AdamW semantics, libs/utils/optimizer.py:33-35) over flat parameter / gradient /
  * moment arrays; elements [0, n_decay) get decoupled weight decay.  n % 4 == 0.  step: device int64, 1-based, already
  * incremented by the caller for this step.  lr_dev (optional): DEVICE pointer to the learning rate; when non-NULL it

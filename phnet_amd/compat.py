@@ -1,11 +1,13 @@
 """Registers the phnet_amd drop-in modules under the reference's import paths, so that
-`from libs.models.Router4OL import RouterOL`, `from libs.utils.loss4OLV3 import Criterion4OL` and
+`from libs.models.Router4OL import RouterOL` (`libs.models.Router4OLV2` for testOLV3.py:11), `from libs.utils.loss4OLV3 import Criterion4OL` and
 `from libs.ops import nms` (trainOL.py:12-14, testOL.py:19-23, Router4OL.py:10) resolve to the HIP-backed classes."""
 import importlib
 import sys
 
 _MAP = {
     "libs.models.Router4OL": "phnet_amd.libs.models.Router4OL",
+    "libs.models.Router4OLV2": "phnet_amd.libs.models.Router4OLV2",
+    "libs.models.fpnV2": "phnet_amd.libs.models.fpnV2",
     "libs.models.resnet": "phnet_amd.libs.models.resnet",
     "libs.models.fpn": "phnet_amd.libs.models.fpn",
     "libs.models.Router": "phnet_amd.libs.models.Router",

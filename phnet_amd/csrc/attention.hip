@@ -236,6 +236,72 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(const float* __restrict__ 
     }
 }
 
+// Head width 32 (the Router4OLV2 family: d_model 256, 8 heads; Router4OLV2.py:98-103), forward only and without dropout -
+// that family is inference-only.  Same structure as attn_fwd_kernel; K/V tiles in dynamic LDS (2 x Lk x 36 floats > 64 KB at
+// Lk = 240: the self-attention fallback of frames without memory, Router4OLV2.py:320-325).
+constexpr int DW = 32, DWP = DW + 4;
+__global__ __launch_bounds__(NT) void attn_fwd_wide_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                           const unsigned char* __restrict__ key_valid, float* __restrict__ o,
+                                                           float* __restrict__ lse, AttnShape g)
+{
+    extern __shared__ __attribute__((aligned(16))) float wide_lds[];
+    __shared__ unsigned char valid[MAXK];
+    float (*Ks)[DWP] = reinterpret_cast<float (*)[DWP]>(wide_lds);
+    float (*Vs)[DWP] = reinterpret_cast<float (*)[DWP]>(wide_lds + (size_t)g.Lk * DWP);
+    const int h = blockIdx.x, row = blockIdx.y * ROWS + threadIdx.x / LPR, part = threadIdx.x % LPR;
+    {
+        const size_t b = blockIdx.z;
+        q += b * g.Lq * g.sq; k += b * g.Lk * g.sk; v += b * g.Lk * g.sv; o += b * g.Lq * g.so; lse += b * g.H * g.Lq;
+        if (key_valid) key_valid += b * g.Lk;
+    }
+    const bool live = row < g.Lq;
+    float qr[DW];
+    {
+        const f4* qp = reinterpret_cast<const f4*>(q + (size_t)(live ? row : 0) * g.sq + h * DW);
+#pragma unroll
+        for (int c = 0; c < DW / 4; ++c) {
+            const f4 t = qp[c];
+            qr[4 * c] = t.x * g.scale; qr[4 * c + 1] = t.y * g.scale; qr[4 * c + 2] = t.z * g.scale; qr[4 * c + 3] = t.w * g.scale;
+        }
+    }
+    for (int idx = threadIdx.x; idx < g.Lk * (DW / 4); idx += NT) {
+        const int r = idx / (DW / 4), c = (idx - r * (DW / 4)) * 4;
+        *reinterpret_cast<f4*>(&Ks[r][c]) = *reinterpret_cast<const f4*>(k + (size_t)r * g.sk + h * DW + c);
+        *reinterpret_cast<f4*>(&Vs[r][c]) = *reinterpret_cast<const f4*>(v + (size_t)r * g.sv + h * DW + c);
+    }
+    for (int i = threadIdx.x; i < g.Lk; i += NT) valid[i] = key_valid ? key_valid[i] : 1;
+    __syncthreads();
+    float m = -INFINITY, l = 0.f, acc[DW];
+#pragma unroll
+    for (int d = 0; d < DW; ++d) acc[d] = 0.f;
+    for (int kk = part; kk < g.Lk; kk += LPR) {
+        if (!valid[kk]) continue;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+        for (int d = 0; d < DW; d += 4) {
+            s0 += qr[d] * Ks[kk][d]; s1 += qr[d + 1] * Ks[kk][d + 1]; s2 += qr[d + 2] * Ks[kk][d + 2]; s3 += qr[d + 3] * Ks[kk][d + 3];
+        }
+        const float s = (s0 + s1) + (s2 + s3);
+        const float mn = fmaxf(m, s);
+        const float c = expf(m - mn), e = expf(s - mn);
+        l = l * c + e;
+#pragma unroll
+        for (int d = 0; d < DW; ++d) acc[d] = acc[d] * c + e * Vs[kk][d];
+        m = mn;
+    }
+    const float mt = quad_max(m);
+    const float c = (m == -INFINITY) ? 0.f : expf(m - mt);
+    l = quad_sum(l * c);
+#pragma unroll
+    for (int d = 0; d < DW; ++d) acc[d] = quad_sum(acc[d] * c);
+    if (live && part == 0) {
+        const float inv = l > 0.f ? 1.0f / l : 0.f;
+#pragma unroll
+        for (int d = 0; d < DW; ++d) o[(size_t)row * g.so + h * DW + d] = acc[d] * inv;
+        lse[(size_t)h * g.Lq + row] = mt + logf(l);
+    }
+}
+
 bool attn_ok(int Lq, int Lk, int H, int E) { return Lq >= 1 && Lk >= 1 && Lq <= MAXK && Lk <= MAXK && H >= 1 && E == H * D; }
 // float4 staging: rows 16-byte aligned
 bool aligned16(const void* p, int64_t stride) { return ((uintptr_t)p & 15) == 0 && (stride & 3) == 0; }
@@ -247,12 +313,26 @@ bool aligned16(const void* p, int64_t stride) { return ((uintptr_t)p & 15) == 0 
 // q [Lq][.] row stride sq, k/v [Lk][.] row strides sk/sv (heads packed along the row: column h*16+d); o [Lq][.] stride so;
 // key_valid (optional) u8[Lk]; dropout of the attention weights either by an explicit mask keep u8[H][Lq][Lk] (kept weights
 // scaled by keep_scale) or, when keep is NULL and rng_state/drop_p are given, by the counter-based mask of common.h
-// (site id rng_call, scale 1/(1-p)); lse [H][Lq] saved for the backward.  Lq, Lk <= 256, head width 16.
+// (site id rng_call, scale 1/(1-p)); lse [H][Lq] saved for the backward.  Lq, Lk <= 256, head width 16 (E = 16 H); the forward
+// also takes head width 32 (E = 32 H) without dropout (keep = NULL, drop_p = 0): the inference-only Router4OLV2 family.
 PHNET_API int phnet_attention_fwd(const float* q, const float* k, const float* v, const uint8_t* key_valid, const uint8_t* keep,
                                   float* o, float* lse, int32_t B, int32_t Lq, int32_t Lk, int32_t H, int32_t E,
                                   int64_t sq, int64_t sk, int64_t sv, int64_t so, float keep_scale,
                                   const uint64_t* rng_state, uint64_t rng_call, float drop_p, void* stream)
 {
+    if (E == H * DW) {                                   // head width 32: forward only, no dropout (Router4OLV2 family, inference)
+        if (B < 1 || Lq < 1 || Lk < 1 || Lq > MAXK || Lk > MAXK || H < 1 || !q || !k || !v || !o || !lse || keep ||
+            (rng_state && drop_p > 0.f)) return PHNET_ERR_ARG;
+        if (!aligned16(k, sk) || !aligned16(v, sv) || !aligned16(q, sq)) return PHNET_ERR_ARG;
+        const size_t lds = (size_t)2 * Lk * DWP * sizeof(float);
+        if (lds > 64 * 1024 &&
+            hipFuncSetAttribute((const void*)attn_fwd_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return PHNET_ERR_LAUNCH;
+        AttnShape gw{Lq, Lk, H, sq, sk, sv, so, 1.0f / sqrtf((float)DW), 1.0f};
+        hipLaunchKernelGGL(attn_fwd_wide_kernel, dim3(H, (Lq + ROWS - 1) / ROWS, B), dim3(NT), lds, (hipStream_t)stream,
+                           q, k, v, key_valid, o, lse, gw);
+        return phnet_launch_status();
+    }
     if (B < 1 || !attn_ok(Lq, Lk, H, E) || !q || !k || !v || !o || !lse || drop_p < 0.f || drop_p >= 1.f) return PHNET_ERR_ARG;
     if (!aligned16(k, sk) || !aligned16(v, sv) || !aligned16(q, sq)) return PHNET_ERR_ARG;
     const DropRng rng = keep ? DropRng{nullptr, 0, 0u} : phnet_make_rng(rng_state, rng_call, drop_p);

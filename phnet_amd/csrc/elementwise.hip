@@ -367,8 +367,9 @@ PHNET_API int phnet_gate_tail_bwd(const float* dout, const float* out, const flo
 PHNET_API int phnet_blend_priors(const float* gate, const float* a, const float* b, const int64_t* idx, float* priors, float* on_map,
                                  int32_t N, int32_t W, int32_t P, void* stream)
 {
-    if (N < 1 || W < 7 || P < 1 || P > W || !gate || !a || !b || !idx || !priors || !on_map) return PHNET_ERR_ARG;
-    hipLaunchKernelGGL(blend_priors_kernel, dim3((N * W + NT - 1) / NT), dim3(NT), 0, (hipStream_t)stream, gate, a, b,
+    if (N < 1 || W < 7 || P < 1 || !gate || !a || !b || !idx || !priors || !on_map) return PHNET_ERR_ARG;
+    const int cols = W > P ? W : P;                     // P > W: the V2 family samples 96 positions out of 72 offsets (repeats)
+    hipLaunchKernelGGL(blend_priors_kernel, dim3((N * cols + NT - 1) / NT), dim3(NT), 0, (hipStream_t)stream, gate, a, b,
                        (const long long*)idx, priors, on_map, N, W, P);
     return phnet_launch_status();
 }

@@ -74,6 +74,43 @@ __global__ __launch_bounds__(ROI_THREADS) void roi_pool_fwd_kernel(
     if (out_cp) out_cp[(bn * ROI_C + lane) * P + k] = acc;       // [B][N][C][P] copy for the routing gate
 }
 
+// Any channel count C <= 64 (the Router4OLV2 family pools 64 / 32 / 16 channels per pyramid level, Router4OLV2.py:143-161):
+// one thread per (sample, channel); C consecutive lanes read one contiguous C*4-byte corner line.  Forward only.
+__global__ __launch_bounds__(ROI_THREADS) void roi_pool_fwd_any_kernel(
+    const float* __restrict__ fmap, const float* __restrict__ xs, const float* __restrict__ ys,
+    float* __restrict__ out, float* __restrict__ out_cp, int B, int N, int P, int h, int w, int C)
+{
+    const long id = (long)blockIdx.x * ROI_THREADS + threadIdx.x;
+    if (id >= (long)B * N * P * C) return;
+    const int ch = (int)(id % C);
+    const long sample = id / C;
+    const int k = (int)(sample % P);
+    const long bn = sample / P;
+    const int b = (int)(bn / N);
+    const float xn = xs[bn * P + (P - 1 - k)];
+    const float yn = ys[k];
+    float acc = 0.0f;
+    if (isfinite(xn)) {
+        const Corners c = corners_of(xn, yn, h, w);
+        const float* base = fmap + (size_t)b * h * w * C + ch;
+        const bool x0in = c.x0 >= 0 && c.x0 < w, x1in = c.x0 + 1 >= 0 && c.x0 + 1 < w;
+        const bool y0in = c.y0 >= 0 && c.y0 < h, y1in = c.y0 + 1 >= 0 && c.y0 + 1 < h;
+        float vnw = 0.f, vne = 0.f, vsw = 0.f, vse = 0.f;
+        if (y0in && x0in) vnw = base[((size_t)c.y0 * w + c.x0) * C];
+        if (y0in && x1in) vne = base[((size_t)c.y0 * w + c.x0 + 1) * C];
+        if (y1in && x0in) vsw = base[((size_t)(c.y0 + 1) * w + c.x0) * C];
+        if (y1in && x1in) vse = base[((size_t)(c.y0 + 1) * w + c.x0 + 1) * C];
+        acc = vnw * c.nw;
+        acc += vne * c.ne;
+        acc += vsw * c.sw;
+        acc += vse * c.se;
+    } else {
+        acc = xn * 0.0f;
+    }
+    out[sample * C + ch] = acc;
+    if (out_cp) out_cp[(bn * C + ch) * P + k] = acc;
+}
+
 __global__ __launch_bounds__(ROI_THREADS) void roi_pool_bwd_kernel(
     const float* __restrict__ dout, const float* __restrict__ fmap, const float* __restrict__ xs,
     const float* __restrict__ ys, float* __restrict__ dmap, float* __restrict__ dxs,
@@ -127,16 +164,22 @@ __global__ __launch_bounds__(ROI_THREADS) void roi_pool_bwd_kernel(
 
 }  // namespace
 
-// fmap [B][h][w][64] f32 NHWC; xs [B][N][P] normalised anchor x per sample row (un-flipped
-// priors_on_featmap); ys [P] = prior_feat_ys; out [B][N][P][64].
+// fmap [B][h][w][C] f32 NHWC; xs [B][N][P] normalised anchor x per sample row (un-flipped
+// priors_on_featmap); ys [P] = prior_feat_ys; out [B][N][P][C].  C = 64: one wavefront per sample (the V1 head, has a
+// backward); other C <= 64: one thread per (sample, channel), forward only.
 // out_cp (optional): the same samples as [B][N][64][P] (the layout the routing gate consumes).
 PHNET_API int phnet_roi_pool_fwd(const float* fmap, const float* xs, const float* ys, float* out, float* out_cp,
                                  int32_t B, int32_t N, int32_t P, int32_t h, int32_t w, int32_t C, void* stream)
 {
-    if (C != ROI_C || B < 0 || N < 0 || P < 0 || h < 1 || w < 1) return PHNET_ERR_ARG;
+    if (C < 1 || C > ROI_C || B < 0 || N < 0 || P < 0 || h < 1 || w < 1) return PHNET_ERR_ARG;
     const long total = (long)B * N * P;
     if (total == 0) return PHNET_OK;
     if (!fmap || !xs || !ys || !out) return PHNET_ERR_ARG;
+    if (C != ROI_C) {                                   // per-level widths of the Router4OLV2 family (forward only)
+        hipLaunchKernelGGL(roi_pool_fwd_any_kernel, dim3((unsigned)ceil_div64(total * C, ROI_THREADS)), dim3(ROI_THREADS), 0,
+                           (hipStream_t)stream, fmap, xs, ys, out, out_cp, B, N, P, h, w, C);
+        return phnet_launch_status();
+    }
     const unsigned blocks = (unsigned)ceil_div64(total, ROI_THREADS / 64);
     hipLaunchKernelGGL(roi_pool_fwd_kernel, dim3(blocks), dim3(ROI_THREADS), 0, (hipStream_t)stream,
                        fmap, xs, ys, out, out_cp, B, N, P, h, w);

@@ -761,6 +761,45 @@ def lane_decode(lines, conf_thresh: float, nms_thresh: float, top_k: int, img_w:
     return out if batched else {k: v[0] for k, v in out.items()}
 
 
+# ------------------------------------------------------------------------------------------------ Router4OLV2 family (inference)
+def gate_v2_fwd(x_cp, w1, s1, t1, w2, s2, t2, wl, bl, out: Optional[torch.Tensor] = None):
+    """x_cp [M,C,P] -> sigmoid(mean(Linear(flatten(conv-bn-relu x2)))) [M]  (csrc/v2head.hip)."""
+    for t, nm in ((x_cp, "x"), (w1, "w1"), (s1, "s1"), (t1, "t1"), (w2, "w2"), (s2, "s2"), (t2, "t2"), (wl, "wl"), (bl, "bl")):
+        _req(t, name=nm)
+    m, c, p = x_cp.shape
+    c1, c2 = w1.shape[0], w2.shape[0]
+    if w1.numel() != c1 * c * 3 or w2.numel() != c2 * c1 or wl.numel() != p * c2 * p or bl.numel() != p:
+        raise RuntimeError("gate_v2_fwd: parameter shapes do not match the feature map")
+    if out is None:
+        out = torch.empty((m,), dtype=torch.float32, device=x_cp.device)
+    check(lib().phnet_gate_v2_fwd(_ptr(x_cp), _ptr(w1), _ptr(s1), _ptr(t1), _ptr(w2), _ptr(s2), _ptr(t2), _ptr(wl), _ptr(bl), _ptr(out),
+                                  m, c, p, c1, c2, _stream()), "phnet_gate_v2_fwd")
+    return out
+
+
+def dyn_bmm_ln_relu_fwd_any(x, w, gamma, beta, eps: float):
+    """x [N,P,K], w [N,K,J] -> relu(LayerNorm(x @ w)) [N,P,J] at run-time shapes (forward only)."""
+    _req(x, name="x"); _req(w, name="w"); _req(gamma, name="gamma"); _req(beta, name="beta")
+    n, p, k = x.shape
+    j = w.shape[2]
+    assert w.shape[0] == n and w.shape[1] == k and gamma.numel() == j
+    y = torch.empty((n, p, j), dtype=torch.float32, device=x.device)
+    check(lib().phnet_dyn_bmm_ln_relu_fwd_any(_ptr(x), _ptr(w), _ptr(gamma), _ptr(beta), _ptr(y), n, p, k, j, float(eps), _stream()),
+          "phnet_dyn_bmm_ln_relu_fwd_any")
+    return y
+
+
+def route_lines(gates, a, b, hard: bool):
+    """gates [S,M] (one row per refinement stage), a / b [M,W] -> [M,W]: hard selection or soft blend by the mean gate."""
+    _req(gates, name="gates"); _req(a, name="a"); _req(b, name="b")
+    s, m = gates.shape
+    w = a.shape[-1]
+    assert a.numel() == m * w and b.numel() == m * w
+    out = torch.empty_like(a)
+    check(lib().phnet_route_lines(_ptr(gates), _ptr(a), _ptr(b), _ptr(out), s, m, w, int(bool(hard)), _stream()), "phnet_route_lines")
+    return out
+
+
 DEFAULT_MMA = "bf16x3"
 
 

@@ -148,6 +148,32 @@ def encoder_fwd_schedule(enc, training: bool, frames: torch.Tensor):
     return tuple(outs), ctx
 
 
+def encoder_fwd_v2(enc, frames: torch.Tensor):
+    """Inference schedule of the Router4OLV2 family's encoder (libs/models/Router4OLV2.py:20-30, libs/models/fpnV2.py:122-150):
+    the trunk WITHOUT its last stage (`self.backbone(x)[:-1]`: layer4 is computed by the reference and thrown away - it is not
+    run here), then the per-level-width FPN: 1x1 laterals (64/128/256 -> 16/32/64), top-down path with a 1x1 projection of the
+    coarser level to the finer level's width BEFORE the nearest resize, 3x3 output convolutions.  BatchNorm in its folded
+    eval form.  Returns the three levels fine -> coarse as NHWC [T,h,w,C_l]."""
+    model, neck = enc.backbone.model, enc.neck
+    tape = []
+    x = K.nchw3_to_nhwc4(frames.contiguous())
+    w_stem = K.pad_channels(ohwi(model.conv1.weight).view(-1, 3), 4).view(model.conv1.out_channels, 7, 7, 4)
+    y = _conv_bn(tape, x, model.conv1, model.bn1, False, relu=True, w_override=w_stem)
+    y, _ = K.maxpool_fwd(y)
+    stages = []
+    for name in ("layer1", "layer2", "layer3"):
+        for blk in getattr(model, name):
+            h = _conv_bn(tape, y, blk.conv1, blk.bn1, False, relu=True)
+            idn = y if blk.downsample is None else _conv_bn(tape, y, blk.downsample[0], blk.downsample[1], False, relu=False)
+            y = _conv_bn(tape, h, blk.conv2, blk.bn2, False, relu=True, residual=idn)
+        stages.append(y)
+    conv = lambda m, t, pad: K.conv2d_fwd(t, ohwi(m.conv.weight), m.conv.bias.detach(), 1, pad)      # noqa: E731
+    lats = [conv(m, f, 0) for m, f in zip(neck.lateral_convs, stages)]
+    for i in range(len(lats) - 1, 0, -1):
+        K.upsample_add_(lats[i - 1], conv(neck.upsample_convs[i - 1], lats[i], 0))
+    return tuple(conv(m, l, 1) for m, l in zip(neck.fpn_convs, lats))
+
+
 def encoder_bwd_schedule(ctx: _Tape, d3, d4, d5, stage_done: Optional[Callable[[str], None]] = None) -> List:
     """Backward of the whole encoder; returns the per-parameter gradients that were NOT written straight into a gradient
     arena (list aligned with enc.parameters(), None where the arena took them)."""
