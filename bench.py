@@ -364,7 +364,7 @@ def main():
         if records:
             # GEMM launches are grouped by kernel symbol (what rocprofv3 --stats also groups by)
             agg = {}
-            for sym, splits, flops, e0, e1, _launch in records:
+            for sym, splits, flops, e0, e1, _launch in (r[:6] for r in records):
                 a = agg.setdefault(sym, [0, 0.0, 0.0])
                 a[0] += 1; a[1] += flops; a[2] += e0.elapsed_time(e1) * 1e-3
             if isolated:

@@ -99,14 +99,14 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(const float* __restrict__ 
 #pragma unroll
     for (int d = 0; d < D; ++d) acc[d] = 0.f;
     const unsigned char* kp = keep ? keep + ((size_t)h * g.Lq + (live ? row : 0)) * g.Lk : nullptr;
-    const uint64_t seed = phnet_rng_seed(rng), rbase = (((uint64_t)blockIdx.z * g.H + h) * g.Lq + (live ? row : 0)) * g.Lk;
+    const uint64_t seed = phnet_rng_seed(rng), rbase = ((uint64_t)h * g.Lq + (live ? row : 0)) * g.Lk;      // within batch entry blockIdx.z
     for (int kk = part; kk < g.Lk; kk += LPR) {
         if (!valid[kk]) continue;
         const float s = dot16(qr, Ks[kk]);
         const float mn = fmaxf(m, s);
         const float c = expf(m - mn), e = expf(s - mn);
         l = l * c + e;
-        const bool kept = kp ? kp[kk] != 0 : (!rng.thresh || phnet_rng_keep(seed, rbase + kk, rng.thresh));
+        const bool kept = kp ? kp[kk] != 0 : (!rng.thresh || phnet_rng_keep(seed, phnet_rng_index_b(rng, blockIdx.z, rbase + kk), rng.thresh));
         const float ed = kept ? e * g.keep_scale : 0.f;
 #pragma unroll
         for (int d = 0; d < D; ++d) acc[d] = acc[d] * c + ed * Vs[kk][d];
@@ -146,7 +146,6 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(const float* __restrict__ 
         if (key_valid) key_valid += b * g.Lk;
         if (keep) keep += b * g.H * g.Lq * g.Lk;
     }
-    const uint64_t ebase = (uint64_t)blockIdx.z * g.H * g.Lq * g.Lk;        // element index base of the dropout generator
     const bool dq_role = (int)blockIdx.y < q_tiles;
     const int tile = dq_role ? blockIdx.y : blockIdx.y - q_tiles;
     const int row = tile * ROWS + threadIdx.x / LPR, part = threadIdx.x % LPR;
@@ -172,7 +171,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(const float* __restrict__ 
         stage_pair(k, g.sk, v, g.sv, h, g.Lk, As, Bs, 1.0f);
         __syncthreads();
         const unsigned char* kp = keep ? keep + ((size_t)h * g.Lq + r) * g.Lk : nullptr;
-        const uint64_t rbase = ebase + ((uint64_t)h * g.Lq + r) * g.Lk;
+        const uint64_t rbase = ((uint64_t)h * g.Lq + r) * g.Lk;
         float acc[D];
 #pragma unroll
         for (int d = 0; d < D; ++d) acc[d] = 0.f;
@@ -181,7 +180,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(const float* __restrict__ 
             const float s = dot16(qr, As[kk]);
             float dp = dot16(dor, Bs[kk]);
             const float p = expf(s - L);
-            const bool kept = kp ? kp[kk] != 0 : (!rng.thresh || phnet_rng_keep(seed, rbase + kk, rng.thresh));
+            const bool kept = kp ? kp[kk] != 0 : (!rng.thresh || phnet_rng_keep(seed, phnet_rng_index_b(rng, blockIdx.z, rbase + kk), rng.thresh));
             dp = kept ? dp * g.keep_scale : 0.f;
             const float ds = p * (dp - delta);
 #pragma unroll
@@ -219,7 +218,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(const float* __restrict__ 
                 const float s = dot16(kr, As[qq]), dp = dot16(vr, Bs[qq]);
                 const float p = expf(s - Ls[qq]);
                 const uint64_t ei = ((uint64_t)h * g.Lq + qq) * g.Lk + r;
-                const bool kept = keep ? keep[ei] != 0 : (!rng.thresh || phnet_rng_keep(seed, ebase + ei, rng.thresh));
+                const bool kept = keep ? keep[ei] != 0 : (!rng.thresh || phnet_rng_keep(seed, phnet_rng_index_b(rng, blockIdx.z, ei), rng.thresh));
                 const float pd = kept ? p * g.keep_scale : 0.f;       // dropped attention weight
                 const float ds = p * ((kept ? dp * g.keep_scale : 0.f) - Dl[qq]);
 #pragma unroll
@@ -335,7 +334,7 @@ PHNET_API int phnet_attention_fwd(const float* q, const float* k, const float* v
     }
     if (B < 1 || !attn_ok(Lq, Lk, H, E) || !q || !k || !v || !o || !lse || drop_p < 0.f || drop_p >= 1.f) return PHNET_ERR_ARG;
     if (!aligned16(k, sk) || !aligned16(v, sv) || !aligned16(q, sq)) return PHNET_ERR_ARG;
-    const DropRng rng = keep ? DropRng{nullptr, 0, 0u} : phnet_make_rng(rng_state, rng_call, drop_p);
+    const DropRng rng = keep ? DropRng{nullptr, 0, 0u, 0u, 0u} : phnet_make_rng(rng_state, rng_call, drop_p);
     AttnShape g{Lq, Lk, H, sq, sk, sv, so, 1.0f / sqrtf((float)D), keep ? keep_scale : (rng.thresh ? 1.0f / (1.0f - drop_p) : 1.0f)};
     hipLaunchKernelGGL(attn_fwd_kernel, dim3(H, (Lq + ROWS - 1) / ROWS, B), dim3(NT), 0, (hipStream_t)stream,
                        q, k, v, key_valid, keep, o, lse, g, rng);
@@ -352,7 +351,7 @@ PHNET_API int phnet_attention_bwd(const float* q, const float* k, const float* v
     if (B < 1 || !attn_ok(Lq, Lk, H, E) || !q || !k || !v || !o || !dout || !lse || !dq || !dk || !dv || drop_p < 0.f || drop_p >= 1.f)
         return PHNET_ERR_ARG;
     if (!aligned16(k, sk) || !aligned16(v, sv) || !aligned16(q, sq) || !aligned16(dout, so) || !aligned16(o, so)) return PHNET_ERR_ARG;
-    const DropRng rng = keep ? DropRng{nullptr, 0, 0u} : phnet_make_rng(rng_state, rng_call, drop_p);
+    const DropRng rng = keep ? DropRng{nullptr, 0, 0u, 0u, 0u} : phnet_make_rng(rng_state, rng_call, drop_p);
     AttnShape g{Lq, Lk, H, sq, sk, sv, so, 1.0f / sqrtf((float)D), keep ? keep_scale : (rng.thresh ? 1.0f / (1.0f - drop_p) : 1.0f)};
     const int qt = (Lq + ROWS - 1) / ROWS, kt = (Lk + ROWS - 1) / ROWS;
     hipLaunchKernelGGL(attn_bwd_kernel, dim3(H, qt + kt, B), dim3(NT), 0, (hipStream_t)stream,

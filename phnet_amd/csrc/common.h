@@ -49,7 +49,12 @@ __device__ __forceinline__ float wave_max(float v) {
 // dropout site of the step has a host-side call id.  Element idx of site `call` is kept iff the splitmix64 finaliser of
 // (state, call, idx) clears the threshold p * 2^32 - the backward kernels recompute the same bit instead of reading a
 // stored mask.
-struct DropRng { const uint64_t* state; uint64_t call; uint32_t thresh; };
+// Items: a launch may cover several independent ITEMS (the (frame, stage) passes of branch B whose backward runs as one batch,
+// or the clips of a batched step); element `local` of item `item` draws bit (item << 32 | local), so a launch over ONE item
+// (item0 = its number, item_elems = 0) and a launch over a batch of items (item0 = 0, item_elems = elements per item) see the
+// same masks.  Both numbers travel inside the 64-bit `rng_call` argument of the C-ABI: bits 0-19 site id, bits 20-31 item0,
+// bits 32-63 item_elems (0 = the whole launch is one item).
+struct DropRng { const uint64_t* state; uint64_t call; uint32_t thresh; uint32_t item0; uint32_t item_elems; };
 
 __device__ __forceinline__ uint64_t phnet_mix64(uint64_t z) {
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -62,8 +67,17 @@ __device__ __forceinline__ uint64_t phnet_rng_seed(const DropRng& r) {
 __device__ __forceinline__ bool phnet_rng_keep(uint64_t seed, uint64_t idx, uint32_t thresh) {
     return (uint32_t)(phnet_mix64(seed + (idx + 1) * 0x9E3779B97F4A7C15ull) >> 32) >= thresh;
 }
+// generator index of flat element idx of an elementwise launch
+__device__ __forceinline__ uint64_t phnet_rng_index(const DropRng& r, uint64_t idx) {
+    if (r.item_elems) return ((uint64_t)(r.item0 + (uint32_t)(idx / r.item_elems)) << 32) | (idx % r.item_elems);
+    return ((uint64_t)r.item0 << 32) | idx;
+}
+// generator index of element `local` of batch entry b (kernels whose grid carries the batch index)
+__device__ __forceinline__ uint64_t phnet_rng_index_b(const DropRng& r, uint32_t b, uint64_t local) {
+    return ((uint64_t)(r.item0 + b) << 32) | local;
+}
 static inline DropRng phnet_make_rng(const uint64_t* state, uint64_t call, float p) {
-    DropRng r{state, call, 0u};
+    DropRng r{state, call & 0xFFFFFull, 0u, (uint32_t)((call >> 20) & 0xFFFu), (uint32_t)(call >> 32)};
     if (state && p > 0.f) r.thresh = (uint32_t)fmin(4294967295.0, (double)p * 4294967296.0);
     return r;
 }

@@ -19,7 +19,7 @@ __global__ __launch_bounds__(NT) void dropout_add_kernel(const float* __restrict
 {
     const long i = (long)blockIdx.x * NT + threadIdx.x;
     if (i >= n) return;
-    const bool kept = !rng.thresh || phnet_rng_keep(phnet_rng_seed(rng), (uint64_t)i, rng.thresh);
+    const bool kept = !rng.thresh || phnet_rng_keep(phnet_rng_seed(rng), phnet_rng_index(rng, (uint64_t)i), rng.thresh);
     const float v = kept ? x[i] * scale : 0.f;
     y[i] = res ? res[i] + v : v;
 }
@@ -35,7 +35,7 @@ __global__ __launch_bounds__(NT) void gelu_dropout_fwd_kernel(const float* __res
 {
     const long i = (long)blockIdx.x * NT + threadIdx.x;
     if (i >= n) return;
-    const bool kept = !rng.thresh || phnet_rng_keep(phnet_rng_seed(rng), (uint64_t)i, rng.thresh);
+    const bool kept = !rng.thresh || phnet_rng_keep(phnet_rng_seed(rng), phnet_rng_index(rng, (uint64_t)i), rng.thresh);
     y[i] = kept ? gelu_erf(x[i]) * scale : 0.f;
 }
 __global__ __launch_bounds__(NT) void gelu_dropout_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(NT) void gelu_dropout_bwd_kernel(const float* __res
 {
     const long i = (long)blockIdx.x * NT + threadIdx.x;
     if (i >= n) return;
-    const bool kept = !rng.thresh || phnet_rng_keep(phnet_rng_seed(rng), (uint64_t)i, rng.thresh);
+    const bool kept = !rng.thresh || phnet_rng_keep(phnet_rng_seed(rng), phnet_rng_index(rng, (uint64_t)i), rng.thresh);
     dx[i] = kept ? dy[i] * scale * gelu_erf_grad(x[i]) : 0.f;
 }
 

@@ -230,7 +230,7 @@ __global__ __launch_bounds__(NT) void dropout_add_ln_fwd_kernel(
         const int i = lane + 64 * u;
         t[u] = 0.f;
         if (i < L) {
-            const bool kept = !rng.thresh || phnet_rng_keep(seed, (uint64_t)(o + i), rng.thresh);
+            const bool kept = !rng.thresh || phnet_rng_keep(seed, phnet_rng_index(rng, (uint64_t)(o + i)), rng.thresh);
             t[u] = res[o + i] + (kept ? x[o + i] * scale : 0.f);
             t_out[o + i] = t[u];
             s += t[u];
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(NT) void dropout_add_ln_bwd_kernel(
                 float gt = rs * (g[u] * w[i] - s1 - xh[u] * s2);
                 if (dt) gt += dt[o + i];
                 dres[o + i] = gt;
-                const bool kept = !rng.thresh || phnet_rng_keep(seed, (uint64_t)(o + i), rng.thresh);
+                const bool kept = !rng.thresh || phnet_rng_keep(seed, phnet_rng_index(rng, (uint64_t)(o + i)), rng.thresh);
                 dx[o + i] = kept ? gt * scale : 0.f;
             }
         }

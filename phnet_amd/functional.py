@@ -314,14 +314,39 @@ class DropoutStream:
         ring[cls._slot[key]:cls._slot[key] + 1].add_(cls.SLOTS)
         cls._calls = 0
 
+    _item = None          # (item0, item_rows) while inside items(): see csrc/common.h "Items"
+
     @classmethod
     def site(cls, device, p: float):
-        """rng triple (counter view, site id, p) for one dropout site, or None when p == 0."""
+        """rng tuple (counter view, site id, p[, item0, item_rows]) for one dropout site, or None when p == 0."""
         if p <= 0.0:
             return None
         ring, key = cls._ring(device), torch.device(device).index
         cls._calls += 1
-        return ring[cls._slot[key]:cls._slot[key] + 1], cls._calls, float(p)
+        rng = (ring[cls._slot[key]:cls._slot[key] + 1], cls._calls, float(p))
+        return rng if cls._item is None else rng + cls._item
+
+    @classmethod
+    def items(cls, base: int, item0: int = 0, item_rows: int = 0):
+        """Context: the dropout sites inside are numbered base+1, base+2, ... in program order and draw their masks per ITEM:
+        a pass over ONE item (item0 = its number, item_rows = 0) and a pass over a batch of items (item0 = 0, item_rows = rows
+        per item) that visit the same sites in the same order see the same masks.  This is what lets the (frame, stage) passes
+        of branch B run one by one in the forward and as one batch in the backward (libs/models/Router4OL.py)."""
+        return _ItemScope(cls, base, item0, item_rows)
+
+
+class _ItemScope:
+    def __init__(self, stream, base, item0, item_rows):
+        self.stream, self.base, self.item = stream, int(base), (int(item0), int(item_rows))
+
+    def __enter__(self):
+        self.saved = (self.stream._calls, self.stream._item)
+        self.stream._calls, self.stream._item = self.base, self.item
+        return self
+
+    def __exit__(self, *exc):
+        self.stream._calls, self.stream._item = self.saved
+        return False
 
 
 class _DropoutAdd(torch.autograd.Function):

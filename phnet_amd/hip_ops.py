@@ -31,7 +31,7 @@ def _gemm_symbol(m, co, k, ws_bytes, dgrad, ci_a, in_dil=1):
             f"{_MMA_MODE}, {pf}, {'true' if buf else 'false'}>", sp.value)
 
 
-def _timed_launch(sym_fn, flops, launch):
+def _timed_launch(sym_fn, flops, launch, shape=None):
     """Runs `launch()`.  With the timer on, also records (symbol, split-K factor, FLOPs, start event, end event, launch):
     bench.py re-launches the recorded closures in isolation inside small hipGraphs to get device-side durations that
     are free of host launch gaps (the event pair around a live eager launch includes them for microsecond kernels)."""
@@ -42,7 +42,7 @@ def _timed_launch(sym_fn, flops, launch):
     e0.record()
     out = launch()
     e1.record()
-    TIMER.append((sym, splits, flops, e0, e1, launch))
+    TIMER.append((sym, splits, flops, e0, e1, launch, shape))     # shape: ("fwd" | "dgrad" | "wgrad" | "linbwd", GEMM rows, cols, depth) for tests/tools/gemm_shapes.py
     return out
 
 
@@ -161,11 +161,12 @@ def conv2d_fwd(x, w, bias, stride: int, pad: int, relu: bool = False, out: Optio
         _timed_launch(lambda: _gemm_symbol(m, co, k, need, False, ci), 2.0 * m * co * k,
                       lambda: check(lib().phnet_conv2d_fwd_fused(_ptr(x), _ptr(w), _ptr(bias), _ptr(addend), _ptr(out), _ptr(part), n, hi, wi,
                                                                  ci, co, r, s, stride, pad, int(relu), _ptr(ws), need, _stream()),
-                                    "phnet_conv2d_fwd_fused"))
+                                    "phnet_conv2d_fwd_fused"), shape=("fwd", m, co, k, r))
         return (out, (part, nblk)) if stats else out
     _timed_launch(lambda: _gemm_symbol(m, co, k, need, False, ci), 2.0 * m * co * k,
                   lambda: check(lib().phnet_conv2d_fwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(out), n, hi, wi, ci, co, r, s, stride,
-                                                       pad, int(relu), _ptr(ws), need, _stream()), "phnet_conv2d_fwd"))
+                                                       pad, int(relu), _ptr(ws), need, _stream()), "phnet_conv2d_fwd"),
+                  shape=("fwd", m, co, k, r))
     return out
 
 
@@ -180,7 +181,8 @@ def conv2d_dgrad(dy, w, in_hw: Tuple[int, int], stride: int, pad: int, addend: O
     m, k = n * hi * wi, r * s * co
     _timed_launch(lambda: _gemm_symbol(m, ci, k, need, True, co, stride), 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * co * r * s * ci,
                   lambda: check(lib().phnet_conv2d_dgrad(_ptr(dy), _ptr(w), _ptr(addend), _ptr(dx), n, hi, wi, ci, co, r, s, stride,
-                                                         pad, _ptr(ws), need, _stream()), "phnet_conv2d_dgrad"))
+                                                         pad, _ptr(ws), need, _stream()), "phnet_conv2d_dgrad"),
+                  shape=("dgrad", m, ci, k, r))
     return dx
 
 
@@ -203,7 +205,8 @@ def conv2d_wgrad(dy, x, w_shape, stride: int, pad: int, dw: Optional[torch.Tenso
                            else f"conv_wgrad_kernel<{128 if (co >= 128 and (co < 256 or n * ho * wo > 8192)) else 64}, 64, {_MMA_MODE}, 16, {4 if _MMA_MODE == 3 else 1}, {'true' if _MMA_MODE == 3 else 'false'}>", 0),
                   2.0 * n * ho * wo * co * r * s * ci,
                   lambda: check(lib().phnet_conv2d_wgrad(_ptr(dy), _ptr(x), _ptr(dw), _ptr(dbias), n, hi, wi, ci, co, r, s, stride,
-                                                         pad, int(accumulate), _ptr(ws), need, _stream()), "phnet_conv2d_wgrad"))
+                                                         pad, int(accumulate), _ptr(ws), need, _stream()), "phnet_conv2d_wgrad"),
+                  shape=("wgrad", co, r * s * ci, n * ho * wo, r))
     return dw
 
 
@@ -241,7 +244,7 @@ def linear_bwd(dy2d, x2d, w, dw: torch.Tensor, dbias: Optional[torch.Tensor], ac
     sym = f"linear_bwd_fused_kernel<{'true' if n % 64 == 0 else 'false'}, {'true' if relu_y is not None else 'false'}, {1 if _MMA_MODE == 1 else 0}>"
     _timed_launch(lambda: (sym, 0), 4.0 * m * n * k,
                   lambda: check(lib().phnet_linear_bwd(_ptr(dy2d), _ptr(x2d), _ptr(w), _ptr(relu_y), _ptr(dx), _ptr(dw), _ptr(dbias), m, k, n,
-                                                       int(accumulate), _stream()), "phnet_linear_bwd"))
+                                                       int(accumulate), _stream()), "phnet_linear_bwd"), shape=("linbwd", m, n, k, 1))
     return dx
 
 
@@ -587,12 +590,18 @@ def gate_stack_bwd(gout, x, out, params, saved, grads, eps: float, accumulate: b
                                      n, anchors, c, p, eps, int(accumulate), _ptr(ws), ws.numel(), _stream()), "phnet_gate_stack_bwd")
 
 
-def _rng_args(rng):
-    """rng = None | (state int64[1] device tensor, call id, drop probability) -> the three C arguments."""
+def _rng_args(rng, width: int = 0):
+    """rng = None | (state int64[1] device tensor, site id, drop probability[, item0, item_rows]) -> the three C arguments.
+    Items (csrc/common.h): item0 = number of the first item of this launch, item_rows = rows per item when the launch covers a
+    batch of items (0: the launch is one item); packed into the 64-bit call argument as site | item0 << 20 | item_elems << 32
+    with item_elems = item_rows * width (width = elements per row of the tensor the mask is drawn for)."""
     if rng is None:
         return None, 0, 0.0
-    state, call, p = rng
-    return _ptr(state), int(call), float(p)
+    state, call, p = rng[:3]
+    item0, item_rows = (rng[3], rng[4]) if len(rng) > 3 else (0, 0)
+    elems = int(item_rows) * int(width)
+    assert 0 <= call < (1 << 20) and 0 <= item0 < (1 << 12) and 0 <= elems < (1 << 32), (call, item0, elems)
+    return _ptr(state), int(call) | (int(item0) << 20) | (elems << 32), float(p)
 
 
 def attention_fwd(q, k, v, heads: int, key_valid=None, keep=None, keep_scale: float = 1.0, rng=None, batch: int = 1):
@@ -696,7 +705,7 @@ def dropout_add(x, res=None, rng=None):
     """res + dropout(x) (either part optional) in one launch; dropout_add(dy, None, rng) is the backward of the dropout."""
     _req(x, name="x")
     y = torch.empty_like(x)
-    check(lib().phnet_dropout_add(_ptr(x), _ptr(res), _ptr(y), x.numel(), *_rng_args(rng), _stream()), "phnet_dropout_add")
+    check(lib().phnet_dropout_add(_ptr(x), _ptr(res), _ptr(y), x.numel(), *_rng_args(rng, x.shape[-1]), _stream()), "phnet_dropout_add")
     return y
 
 
@@ -709,7 +718,7 @@ def dropout_add_ln_fwd(x, res, w, b, eps: float, rng=None, save_stats: bool = Tr
     mean = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
     check(lib().phnet_dropout_add_ln_fwd(_ptr(x), _ptr(res), _ptr(w), _ptr(b), _ptr(t), _ptr(h), _ptr(mean), _ptr(rstd), rows, L, eps,
-                                         *_rng_args(rng), _stream()), "phnet_dropout_add_ln_fwd")
+                                         *_rng_args(rng, L), _stream()), "phnet_dropout_add_ln_fwd")
     return t, h, mean, rstd
 
 
@@ -724,7 +733,7 @@ def dropout_add_ln_bwd(dh, dt, t, w, mean, rstd, rng=None, dw: Optional[torch.Te
         dw, db, accumulate = torch.empty_like(w), torch.empty_like(w), False
     ws = workspace(lib().phnet_layernorm_bwd_workspace(rows, L), t.device, 2)
     check(lib().phnet_dropout_add_ln_bwd(_ptr(dh), _ptr(dt), _ptr(t), _ptr(w), _ptr(mean), _ptr(rstd), _ptr(dres), _ptr(dx), _ptr(dw),
-                                         _ptr(db), rows, L, int(accumulate), *_rng_args(rng), _ptr(ws), ws.numel(), _stream()),
+                                         _ptr(db), rows, L, int(accumulate), *_rng_args(rng, L), _ptr(ws), ws.numel(), _stream()),
           "phnet_dropout_add_ln_bwd")
     return dres, dx, dw, db
 
@@ -732,14 +741,14 @@ def dropout_add_ln_bwd(dh, dt, t, w, mean, rstd, rng=None, dw: Optional[torch.Te
 def gelu_dropout_fwd(x, rng=None):
     _req(x, name="x")
     y = torch.empty_like(x)
-    check(lib().phnet_gelu_dropout_fwd(_ptr(x), _ptr(y), x.numel(), *_rng_args(rng), _stream()), "phnet_gelu_dropout_fwd")
+    check(lib().phnet_gelu_dropout_fwd(_ptr(x), _ptr(y), x.numel(), *_rng_args(rng, x.shape[-1]), _stream()), "phnet_gelu_dropout_fwd")
     return y
 
 
 def gelu_dropout_bwd(dy, x, rng=None):
     _req(dy, name="dy")
     dx = torch.empty_like(x)
-    check(lib().phnet_gelu_dropout_bwd(_ptr(dy), _ptr(x), _ptr(dx), x.numel(), *_rng_args(rng), _stream()), "phnet_gelu_dropout_bwd")
+    check(lib().phnet_gelu_dropout_bwd(_ptr(dy), _ptr(x), _ptr(dx), x.numel(), *_rng_args(rng, x.shape[-1]), _stream()), "phnet_gelu_dropout_bwd")
     return dx
 
 

@@ -342,6 +342,63 @@ class DetNetV2(nn.Module):
         return decoded, keep_inds, keep
 
 
+BRANCH_B_SITES = 1 << 10      # dropout site numbering of branch B inside DropoutStream.items (functional.py)
+
+
+class _BranchBDeferred(torch.autograd.Function):
+    """Backward of ALL branch-B passes of a clip as ONE batch.
+
+    Forward dependencies tie the (frame t, stage s) passes of branch B into a chain (the memory of (t, s) is picked by the label
+    assignment of (t' < t, s), its priors are the blend of (t, s-1)), so the forward runs pass by pass on 240 rows - but
+    nothing flows BACK along those links: memory tokens and blended priors are detached (Router4OL.py:292-302, 563-584).  The
+    gradient of a pass needs only d loss / d predictions of that pass, and every pass uses the same decoder / tower weights.
+    So the passes run forward WITHOUT autograd (schedule loop in RouterOL.train_clip_stage_major), and this node recomputes
+    them as one batch (S*T*240 rows per kernel; decoder batch = the S*(T-1) passes that have a memory) with autograd enabled
+    when the gradients of their predictions arrive, and back-propagates through that batch: ~70 launches instead of
+    ~40 per pass x 12-15 passes, at the price of one extra batched forward.  Dropout: both runs draw their masks per ITEM
+    (functional.DropoutStream.items), so the batch sees exactly the masks the passes saw.
+    Inputs that receive gradients: the tokens of each stage [T,N,E], the stage-0 priors [T,N,6+S] and branch B's parameters."""
+
+    @staticmethod
+    def forward(ctx, model, pre_pred, pri_all, rings, valids, n_tok, pri0, *rest):
+        """rest = the n_tok token tensors, then branch B's parameters (inputs of this node so that the OUTER graph reaches them:
+        stock DistributedDataParallel marks parameters it cannot reach from the loss as unused and would see them a second
+        time when the inner backward ran - their gradients are handed back through this node instead)."""
+        ctx.model, ctx.rings, ctx.valids, ctx.n_tok = model, rings, valids, n_tok
+        ctx.params = rest[n_tok:]
+        ctx.save_for_backward(pri_all, *[t.detach() for t in rest[:n_tok]])
+        return pre_pred.view_as(pre_pred)
+
+    @staticmethod
+    def backward(ctx, d_pred):
+        pri_all, *tokens = ctx.saved_tensors
+        det = ctx.model.detNet
+        S, T = len(tokens), tokens[0].shape[0]
+        need_pri = ctx.needs_input_grad[6]
+        wanted = [i for i, p in enumerate(ctx.params) if ctx.needs_input_grad[7 + ctx.n_tok + i]]
+        # the assembled tower weights of this recomputation get their OWN gradient sinks: the inner backward below consumes the
+        # graph that hands a sink's buffer on, so a cache entry must never be shared between two recomputations (several
+        # forward passes before one backward, trainOL.py:205-212) or with the forward that is being built right now
+        outer_cache, det._branch_cache = det._branch_cache, None
+        try:
+            with torch.enable_grad():
+                tok = torch.cat(tokens, dim=0).requires_grad_()                      # [S*T,N,E], item (s, t) at s*T + t
+                pri = pri_all.detach().requires_grad_(need_pri)
+                pred = ctx.model._branch_b_batch(tok, pri, ctx.rings, ctx.valids, S, T)
+                # (arena-backed parameters: the HIP backward kernels accumulate straight into .grad and autograd reports None)
+                grads = torch.autograd.grad([pred], [tok] + ([pri] if need_pri else []) + [ctx.params[i] for i in wanted],
+                                            [d_pred.contiguous()], allow_unused=True)
+        finally:
+            det._branch_cache = outer_cache
+        ctx.rings = ctx.valids = None
+        d_tok = grads[0].split(T, dim=0)
+        d_pri0 = grads[1][:T] if need_pri else None
+        d_par = [None] * len(ctx.params)
+        for j, i in enumerate(wanted):
+            d_par[i] = grads[1 + int(need_pri) + j]
+        return (None, None, None, None, None, None, d_pri0) + tuple(d_tok) + tuple(d_par)
+
+
 class RouterOL(nn.Module):
     def __init__(self, cfg, criterion=None):
         super().__init__()
@@ -357,6 +414,9 @@ class RouterOL(nn.Module):
         # "stage" (every stage's frame-independent front batched over the frames, branch B frame by frame) or "frame" (the
         # reference's loop order)
         self.schedule = "stage"          # measured at T = 5, ResNet-34 320x800: frame 25.0, stage 22.3, wavefront 22.9 ms per step
+        # stage-major schedule only: branch B's passes run forward without autograd and their backward runs as ONE batch
+        # (_BranchBDeferred); False: every pass is its own autograd sub-graph (same arithmetic, same dropout masks)
+        self.defer_branch_b = True
 
     @property
     def stage_major(self):
@@ -469,6 +529,29 @@ class RouterOL(nn.Module):
         self._begin_clip()
         return total_loss
 
+    def _branch_b_batch(self, tok, pri, rings, valids, S: int, T: int):
+        """Branch B of all (stage, frame) items at once: tok [S*T,N,E] tokens, pri [S*T,N,6+S] priors, rings[s] [W+T,L1,E] /
+        valids[s] [W+T,L1] the token rings of each stage (frame t attends to slots t .. t+W-1).  Frames without memory (t = 0)
+        skip the decoder (Router4OL.py:378-382).  Returns the predictions [S*T,N,6+S]."""
+        det = self.detNet
+        N, E, W = det.num_priors, tok.shape[-1], self.save_freq_max
+        feat = tok
+        if T > 1:
+            L1 = rings[0].shape[1]
+            tokv = tok.view(S, T, N, E)
+            tgt = tokv[:, 1:].reshape(S * (T - 1) * N, E)
+            ring = torch.stack(rings) if S > 1 else rings[0].unsqueeze(0)                        # [S,W+T,L1,E]
+            valid = torch.stack(valids) if S > 1 else valids[0].unsqueeze(0)
+            st = ring.stride()
+            mem = ring.as_strided((S, T - 1, W * L1, E), (st[0], st[1], E, 1), ring.storage_offset() + st[1]).reshape(-1, E)
+            sv = valid.stride()
+            key_valid = valid.as_strided((S, T - 1, W * L1), (sv[0], sv[1], 1), valid.storage_offset() + sv[1]).reshape(-1)
+            with PF.DropoutStream.items(BRANCH_B_SITES, 0, N):
+                dec = det.transformer_Dec(tgt=tgt, memory=mem, memory_key_valid=key_valid, batch=S * (T - 1))
+            feat = torch.cat([tokv[:, :1], dec.view(S, T - 1, N, E)], dim=1).reshape(S * T, N, E)
+        pred, _ = det._branch(feat, pri, True)
+        return pred
+
     def train_clip_stage_major(self, frame: torch.Tensor, lanes: torch.Tensor):
         """Training forward of one clip in STAGE-major order.  What ties the frames of a clip together is only branch B's
         memory: stage s of frame t attends to the stage-s tokens of the up to `save_freq_max` frames before it
@@ -476,47 +559,76 @@ class RouterOL(nn.Module):
         predictions.  ROI pooling, routing gate, dynamic head and branch A of stage s depend on frame t alone (through the
         stage-(s-1) blend).  So instead of 15 serial (frame, stage) iterations of ~40 launches on 240 rows, every stage runs
         its frame-independent part ONCE for the whole clip (T*240 rows per kernel, as stage 0 already did) and only
-        branch B + the assignment + the token gather walk the frames.  Same arithmetic per (frame, stage); the matched
+        branch B + the assignment + the token gather walk the frames - forward; branch B's BACKWARD runs as one batch over all
+        (frame, stage) passes (`defer_branch_b`, _BranchBDeferred).  Same arithmetic per (frame, stage); the matched
         anchors that feed the memory come from the stand-alone assignment kernel (the criterion recomputes the identical
         assignment later, tests/test_model_gpu.py)."""
         from phnet_amd import hip_ops as K
         det = self.detNet
-        T = frame.shape[0]
+        T, S, N = frame.shape[0], det.refine_layers, det.num_priors
+        W, L1 = self.save_freq_max, lanes.shape[1] + 1
+        dev = frame.device
         feats = self.backbone(frame)                                           # 3 x [T,h,w,C] NHWC
         levels = list(feats)[::-1]
         det.priors, det.priors_on_featmap = det.generate_priors_from_embeddings()
         priors = det.priors.unsqueeze(0).expand(T, -1, -1)
         on_map = det.priors_on_featmap.unsqueeze(0).expand(T, -1, -1).contiguous()
         pro = det.pro_embedding.weight.unsqueeze(0).expand(T, -1, -1)
+        E = 2 * det.fc_hidden_dim
+        defer = self.defer_branch_b
+        det._branch_weights(True)                                              # assembled WITH autograd, before any no_grad use
         per_frame = [{"predictions_fir": [], "predictions_sec": [], "gates": []} for _ in range(T)]
-        for stage in range(det.refine_layers):
+        pos = det.PositionEmbedding.embed.weight.unsqueeze(0).expand(T, -1, -1)
+        tokens, rings, valids, pre_pred, pri_used = [], [], [], [], []
+        pri0 = priors
+        for stage in range(S):
             front = det.stage_front(levels[stage], stage, priors, on_map, pro)                 # everything [T,...]
-            # branch B's input (content | learned position) of all frames in one cat; per-frame views of it below
-            front["attn"] = torch.cat([front["local"], det.PositionEmbedding.embed.weight.unsqueeze(0).expand(T, -1, -1)], dim=-1)
-            parts = {k: v.split(1, dim=0) for k, v in front.items()}                          # one cat in the backward
-            pri_t = priors.split(1, dim=0) if priors.requires_grad else [priors[t:t + 1] for t in range(T)]
-            # memory tokens of this stage: frame t's slot of one ring buffer, the attention window is a contiguous slice
-            L1 = lanes.shape[1] + 1
-            ring = torch.empty((T, L1, 1, front["attn"].shape[-1]), dtype=torch.float32, device=frame.device)
-            ring_valid = torch.empty((T, L1), dtype=torch.bool, device=frame.device)
-            lines_b = []
+            attn_all = torch.cat([front["local"], pos], dim=-1)                               # branch B's input of all frames [T,N,E]
+            # memory tokens of this stage: a ring with W leading slots that are never valid - frame t's window is ALWAYS
+            # ring[t : t + W] (fixed key positions: the batched backward sees the keys where the forward saw them)
+            ring = torch.zeros((W + T, L1, E), dtype=torch.float32, device=dev)
+            ring_valid = torch.zeros((W + T, L1), dtype=torch.bool, device=dev)
+            if defer:
+                src, pri_src = attn_all.detach(), priors.detach()
+            else:
+                src = attn_all
+                pri_src = priors
+            tok_t = src.split(1, dim=0)
+            pri_t = pri_src.split(1, dim=0) if pri_src.requires_grad else [pri_src[t:t + 1] for t in range(T)]
+            lines_b, preds_b = [], []
             for t in range(T):
-                t0 = max(0, t - self.save_freq_max)
-                mem = (ring[t0:t].view(-1, 1, ring.shape[-1]), ring_valid[t0:t].view(-1)) if t > 0 else None
-                fr = {k: parts[k][t] for k in parts}
-                fr["attn"] = fr["attn"].transpose(0, 1)                                       # [N,1,2C] view
-                r = det.stage_back(fr, stage, pri_t[t], mem)
+                mem = (ring[t:t + W].view(-1, 1, E), ring_valid[t:t + W].view(-1)) if t > 0 else None
+                with torch.set_grad_enabled(not defer), PF.DropoutStream.items(BRANCH_B_SITES, stage * (T - 1) + t - 1 if t else 0, 0):
+                    pred_b, line_b = det.forward_second(mem, tok_t[t].transpose(0, 1), stage, pri_t[t])
                 with torch.no_grad():
-                    _, rows_sorted, _ = K.lane_assign(r["pred_b"][0].detach().contiguous(), lanes[t].contiguous(), det.img_w, det.img_h)
-                    K.memory_tokens(r["attn"].detach().contiguous(), rows_sorted.contiguous(), out=(ring[t], ring_valid[t]))
-                per_frame[t]["predictions_fir"].append(r["pred_a"])
-                per_frame[t]["predictions_sec"].append(r["pred_b"])
-                per_frame[t]["gates"].append(r["gate"])
-                lines_b.append(r["lines_b"].detach())
-            if stage != det.refine_layers - 1:
+                    _, rows_sorted, _ = K.lane_assign(pred_b[0].detach().contiguous(), lanes[t].contiguous(), det.img_w, det.img_h)
+                    K.memory_tokens(tok_t[t].detach().contiguous(), rows_sorted.contiguous(), out=(ring[W + t], ring_valid[W + t]))
+                preds_b.append(pred_b)
+                lines_b.append(line_b.detach())
+            pa = front["pred_a"].split(1, dim=0)                                               # one cat in the backward
+            gt = front["gate"].split(1, dim=0)
+            for t in range(T):
+                per_frame[t]["predictions_fir"].append(pa[t])
+                per_frame[t]["gates"].append(gt[t])
+                if not defer:
+                    per_frame[t]["predictions_sec"].append(preds_b[t])
+            if defer:
+                tokens.append(attn_all); rings.append(ring); valids.append(ring_valid)
+                pre_pred.append(torch.cat(preds_b, dim=0)); pri_used.append(pri_src)
+            if stage != S - 1:
                 priors, on_map = K.blend_priors(front["gate"].detach().contiguous(), front["lines_a"].detach().contiguous(),
                                                 torch.cat(lines_b, dim=0), det.sample_x_indexs)
                 pro = front["local"].detach()
+        if defer:
+            params = list(det.transformer_Dec.parameters())
+            for name in ("cls_modules_sec", "reg_modules_sec", "iou_modules_sec", "cls_layers_sec", "reg_layers_sec", "iou_layers_sec"):
+                params += list(getattr(det, name).parameters())
+            pred_all = _BranchBDeferred.apply(self, torch.cat(pre_pred, dim=0), torch.cat(pri_used, dim=0), rings, valids, len(tokens),
+                                              pri0, *tokens, *params)
+            pb = pred_all.split(1, dim=0)                                                      # one cat in the backward
+            for s_ in range(S):
+                for t in range(T):
+                    per_frame[t]["predictions_sec"].append(pb[s_ * T + t])
         total_loss = 0.0
         for t in range(T):
             out = {"predictions_fir": per_frame[t]["predictions_fir"], "predictions_sec": per_frame[t]["predictions_sec"]}

@@ -1053,3 +1053,47 @@ def test_lane_update_fwd_bwd_vs_fp64_statement(ops, N, S, HW):
         dhead2, none = ops.lane_update_bwd(dev(gp.float()) if use_p else None, dev(gl.float()) if use_l else None,
                                            got_l, hdv, ysd, img_w, img_h, False)
         assert none is None and torch.equal(dhead2, dhead)
+
+
+def test_dropout_masks_per_item_batched_equals_item_by_item():
+    """csrc/common.h "Items": a launch over a batch of items (item_rows = rows per item) and one launch per item (item0 = its
+    number) draw the same masks - elementwise kernels and the attention core (forward and backward)."""
+    from phnet_amd import hip_ops as K
+    dev = "cuda"
+    state = torch.tensor([123456789], dtype=torch.int64, device=dev)
+    items, rows, L = 5, 37, 128
+    r = np.random.default_rng(3)
+    x = torch.from_numpy(r.standard_normal((items * rows, L)).astype(np.float32)).to(dev)
+    res = torch.from_numpy(r.standard_normal((items * rows, L)).astype(np.float32)).to(dev)
+    w = torch.from_numpy(r.uniform(0.5, 1.5, L).astype(np.float32)).to(dev)
+    b = torch.from_numpy(r.normal(0, 0.1, L).astype(np.float32)).to(dev)
+    whole = (state, 11, 0.3, 0, rows)
+    y = K.dropout_add(x, res, whole)
+    gl = K.gelu_dropout_fwd(x, whole)
+    t, h, _, _ = K.dropout_add_ln_fwd(x, res, w, b, 1e-5, whole)
+    assert 0.2 < float((y == res).float().mean()) < 0.4                     # ~30 % dropped
+    for i in range(items):
+        one = (state, 11, 0.3, i, 0)
+        sl = slice(i * rows, (i + 1) * rows)
+        assert torch.equal(K.dropout_add(x[sl].contiguous(), res[sl].contiguous(), one), y[sl])
+        assert torch.equal(K.gelu_dropout_fwd(x[sl].contiguous(), one), gl[sl])
+        ti, hi, _, _ = K.dropout_add_ln_fwd(x[sl].contiguous(), res[sl].contiguous(), w, b, 1e-5, one)
+        assert torch.equal(ti, t[sl]) and torch.equal(hi, h[sl])
+    assert not torch.equal(K.dropout_add(x[:rows].contiguous(), res[:rows].contiguous(), (state, 11, 0.3, 1, 0)), y[:rows])
+    # attention: batch entry b of a batched launch == a one-entry launch with item0 = b
+    H, D, lq, lk = 8, 16, 48, 20
+    q = torch.from_numpy(r.standard_normal((items * lq, H * D)).astype(np.float32)).to(dev)
+    kv = torch.from_numpy(r.standard_normal((items * lk, 2 * H * D)).astype(np.float32)).to(dev)
+    o, lse = K.attention_fwd(q, kv[:, :H * D], kv[:, H * D:], H, None, rng=(state, 12, 0.3, 0, 0), batch=items)
+    do = torch.from_numpy(r.standard_normal((items * lq, H * D)).astype(np.float32)).to(dev)
+    dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+    K.attention_bwd(q, kv[:, :H * D], kv[:, H * D:], o, do, lse, H, dq, dkv[:, :H * D], dkv[:, H * D:], None, rng=(state, 12, 0.3, 0, 0), batch=items)
+    for i in range(items):
+        qs, ks = slice(i * lq, (i + 1) * lq), slice(i * lk, (i + 1) * lk)
+        qi, kvi = q[qs].contiguous(), kv[ks].contiguous()
+        oi, lsei = K.attention_fwd(qi, kvi[:, :H * D], kvi[:, H * D:], H, None, rng=(state, 12, 0.3, i, 0))
+        assert torch.equal(oi, o[qs])
+        dqi, dkvi = torch.empty_like(qi), torch.empty_like(kvi)
+        K.attention_bwd(qi, kvi[:, :H * D], kvi[:, H * D:], oi, do[qs].contiguous(), lsei, H, dqi, dkvi[:, :H * D], dkvi[:, H * D:], None,
+                        rng=(state, 12, 0.3, i, 0))
+        assert torch.equal(dqi, dq[qs]) and torch.equal(dkvi, dkv[ks])

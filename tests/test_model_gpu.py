@@ -495,7 +495,7 @@ def test_dropout_masks_advance_with_each_graph_replay_and_match_between_forward_
         assert float(loss_with_pinned_masks(snap + 8)) != float(loss_with_pinned_masks(snap))
 
 
-@pytest.mark.parametrize("schedule", ["stage", "wavefront"])
+@pytest.mark.parametrize("schedule", ["stage", "stage_direct", "wavefront"])
 def test_batched_training_schedules_equal_frame_major(schedule):
     """RouterOL.schedule: "stage" (every stage's frame-independent part batched over the clip's frames, branch B + assignment
     + memory tokens walking the frames) and "wavefront" (the pairs of an anti-diagonal t + s = d share ONE batched branch-B
@@ -508,7 +508,8 @@ def test_batched_training_schedules_equal_frame_major(schedule):
     out = []
     for sched in ("frame", schedule):
         model = _build(g).train()
-        model.schedule = sched
+        model.schedule = sched.split("_")[0]
+        model.defer_branch_b = sched != "stage_direct"          # "stage": branch B's backward as ONE batch (_BranchBDeferred)
         rec, undo = _record_heads(model)
         loss = model({"frame": frames, "lanes": lanes})
         loss.backward()
@@ -528,6 +529,43 @@ def test_batched_training_schedules_equal_frame_major(schedule):
     for k in ga:
         tol = 5e-2 if k.startswith("detNet.router.") else 2e-3             # (gate: one anchor at the ReLU threshold may flip, see below)
         assert abs(ga[k] - gb[k]) <= tol * ga[k] + 1e-5, (k, ga[k], gb[k])
+
+
+def test_deferred_branch_b_backward_sees_the_forward_dropout_masks():
+    """Stage-major schedule WITH dropout (p = 0.1 in the decoder, the reference's setting): the branch-B passes run forward one
+    by one without autograd and backward as one batch that recomputes them (_BranchBDeferred).  Both runs draw their masks per
+    item (DropoutStream.items), so against the same schedule with every pass as its own autograd sub-graph (same masks by
+    construction) the loss is the same number and the gradients agree to re-association noise - which they would not with any
+    other mask (last assertion)."""
+    from phnet_amd import functional as PF
+    g = O.Geometry(img_h=64, img_w=160, arch="resnet18")
+    T = 6
+    frames, lanes = synth.make_clip(g, T, seed=21).cuda(), synth.make_targets(g, T, counts=(3, 2, 0, 4, 1, 3)).cuda()
+    out = []
+    for defer in (False, True, True):
+        model = _build(g).train()
+        for m in model.detNet.transformer_Dec.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.1
+            if isinstance(m, torch.nn.MultiheadAttention):
+                m.dropout = 0.1
+        model.defer_branch_b = defer
+        ring = PF.DropoutStream._ring(frames.device)
+        ring.copy_(torch.arange(PF.DropoutStream.SLOTS, device=frames.device) + 7000 + (len(out) == 2) * 64)   # third run: other masks
+        PF.DropoutStream._slot[frames.device.index] = 0
+        loss = model({"frame": frames, "lanes": lanes})
+        loss.backward()
+        torch.cuda.synchronize()
+        out.append((float(loss), {k: p.grad.double().norm().item() for k, p in model.named_parameters() if p.grad is not None},
+                    model.detNet.transformer_Dec.layers[0].linear1.weight.grad.detach().clone()))
+    (la, ga, wa), (lb, gb, wb), (lc, _, wc) = out
+    assert abs(la - lb) <= 2e-5 * abs(la), (la, lb)
+    assert ga.keys() == gb.keys()
+    for k in ga:
+        assert abs(ga[k] - gb[k]) <= 2e-3 * ga[k] + 1e-5, (k, ga[k], gb[k])
+    rel = float((wa - wb).norm() / wa.norm())
+    assert rel <= 2e-3, rel
+    assert abs(la - lc) > 1e-4 * abs(la) and float((wa - wc).norm() / wa.norm()) > 1e-2      # the masks matter
 
 
 def test_stage0_batched_over_frames_equals_per_frame_stage0():
