@@ -73,47 +73,69 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
     return v;
 }
 
-__global__ __launch_bounds__(NT) void bn_fwd_finalize_kernel(
+// Column sums of the per-block partials [nblk][2][C] in fp64, for FIN_CH channels per workgroup: thread (channel cl, row group g)
+// walks the rows g, g + FIN_G, ... (a wave reads FIN_CH consecutive channels of 8 rows per step), the FIN_G partial sums of a
+// channel are folded through LDS in a fixed tree order (bit-reproducible).  The one-wave-per-channel form this replaces read
+// 4 bytes per 512-byte row stride and needed 15-19 us for the 1250-2500 partial rows of the stem / layer1 BatchNorms.
+constexpr int FIN_CH = 8, FIN_NT = 1024, FIN_G = FIN_NT / FIN_CH;
+
+__device__ __forceinline__ void finalize_column_sums(const float* __restrict__ partial, int nblk, int C, double* red, double& s0, double& s1)
+{
+    const int cl = threadIdx.x % FIN_CH, g = threadIdx.x / FIN_CH;
+    const int c = blockIdx.x * FIN_CH + cl;
+    double a = 0.0, b = 0.0;
+    if (c < C)
+        for (int r = g; r < nblk; r += FIN_G) {
+            a += (double)partial[(size_t)r * 2 * C + c];
+            b += (double)partial[(size_t)r * 2 * C + C + c];
+        }
+    red[threadIdx.x] = a;
+    red[FIN_NT + threadIdx.x] = b;
+    __syncthreads();
+    for (int half = FIN_G / 2; half > 0; half >>= 1) {
+        if (g < half) {
+            red[threadIdx.x] += red[threadIdx.x + half * FIN_CH];
+            red[FIN_NT + threadIdx.x] += red[FIN_NT + threadIdx.x + half * FIN_CH];
+        }
+        __syncthreads();
+    }
+    s0 = red[cl];
+    s1 = red[FIN_NT + cl];
+}
+
+__global__ __launch_bounds__(FIN_NT) void bn_fwd_finalize_kernel(
     const float* __restrict__ partial, int nblk, long M, int C, float eps,
     float momentum, const float* __restrict__ gamma, const float* __restrict__ beta,
     float* __restrict__ running_mean, float* __restrict__ running_var,
     float* __restrict__ save_mean, float* __restrict__ save_invstd,
     float* __restrict__ scale, float* __restrict__ shift, int training)
 {
-    const int c = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (c >= C) return;
-    float mean, invstd;
+    __shared__ double red[2 * FIN_NT];
+    const int c = blockIdx.x * FIN_CH + threadIdx.x % FIN_CH;
+    float mean = 0.f, invstd = 0.f;
     if (training) {
-        double s = 0.0, ss = 0.0;
-        for (int b = lane; b < nblk; b += 64) {
-            s += (double)partial[(size_t)b * 2 * C + c];
-            ss += (double)partial[(size_t)b * 2 * C + C + c];
-        }
-        s = wave_sum_f64(s);
-        ss = wave_sum_f64(ss);
+        double s, ss;
+        finalize_column_sums(partial, nblk, C, red, s, ss);
+        if (threadIdx.x >= FIN_CH || c >= C) return;
         const double mu = s / (double)M;
         double var = ss / (double)M - mu * mu;
         var = var < 0.0 ? 0.0 : var;
         mean = (float)mu;
         invstd = (float)(1.0 / sqrt(var + (double)eps));
-        if (lane == 0) {
-            if (running_mean) {
-                const double unbiased = M > 1 ? var * (double)M / (double)(M - 1) : var;
-                running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
-                running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
-            }
-            if (save_mean) { save_mean[c] = mean; save_invstd[c] = invstd; }
+        if (running_mean) {
+            const double unbiased = M > 1 ? var * (double)M / (double)(M - 1) : var;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
         }
+        if (save_mean) { save_mean[c] = mean; save_invstd[c] = invstd; }
     } else {
+        if (threadIdx.x >= FIN_CH || c >= C) return;
         mean = running_mean[c];
         invstd = 1.0f / sqrtf(running_var[c] + eps);
     }
-    if (lane == 0) {
-        const float sc = gamma[c] * invstd;
-        scale[c] = sc;
-        shift[c] = beta[c] - mean * sc;
-    }
+    const float sc = gamma[c] * invstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - mean * sc;
 }
 
 // y = x*scale[c] + shift[c] (+ residual) (relu)
@@ -131,21 +153,15 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ 
     reinterpret_cast<f32x4*>(y)[i] = v;
 }
 
-__global__ __launch_bounds__(NT) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, long M, int C,
-                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                             float* __restrict__ c1, float* __restrict__ c2, int accumulate)
+__global__ __launch_bounds__(FIN_NT) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, long M, int C,
+                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                 float* __restrict__ c1, float* __restrict__ c2, int accumulate)
 {
-    const int c = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (c >= C) return;
-    double s = 0.0, sx = 0.0;
-    for (int b = lane; b < nblk; b += 64) {
-        s += (double)partial[(size_t)b * 2 * C + c];
-        sx += (double)partial[(size_t)b * 2 * C + C + c];
-    }
-    s = wave_sum_f64(s);
-    sx = wave_sum_f64(sx);
-    if (lane != 0) return;
+    __shared__ double red[2 * FIN_NT];
+    const int c = blockIdx.x * FIN_CH + threadIdx.x % FIN_CH;
+    double s, sx;
+    finalize_column_sums(partial, nblk, C, red, s, sx);
+    if (threadIdx.x >= FIN_CH || c >= C) return;
     if (accumulate) { dgamma[c] += (float)sx; dbeta[c] += (float)s; }
     else { dgamma[c] = (float)sx; dbeta[c] = (float)s; }
     c1[c] = (float)(s / (double)M);
@@ -411,7 +427,7 @@ PHNET_API int phnet_bn_fwd_stats(const float* x, int64_t M, int32_t C, float eps
                            x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
                            partial, (long)M, C, rpb, 0);
     } else if (!running_mean || !running_var) return PHNET_ERR_ARG;
-    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 3) / 4), dim3(NT), 0, st, partial, nblk, (long)M, C, eps, momentum,
+    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_NT), 0, st, partial, nblk, (long)M, C, eps, momentum,
                        gamma, beta, running_mean, running_var, save_mean, save_invstd, scale, shift, training);
     return phnet_launch_status();
 }
@@ -423,7 +439,7 @@ PHNET_API int phnet_bn_finalize_partials(const float* partial, int64_t nblk, int
                                          float* save_mean, float* save_invstd, float* scale, float* shift, void* stream)
 {
     if (M < 1 || nblk < 1 || nblk > 0x7fffffff || !channels_ok(C) || !partial || !gamma || !beta || !scale || !shift) return PHNET_ERR_ARG;
-    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 3) / 4), dim3(NT), 0, (hipStream_t)stream, partial, (int)nblk, (long)M, C, eps,
+    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_NT), 0, (hipStream_t)stream, partial, (int)nblk, (long)M, C, eps,
                        momentum, gamma, beta, running_mean, running_var, save_mean, save_invstd, scale, shift, 1);
     return phnet_launch_status();
 }
@@ -455,7 +471,7 @@ PHNET_API int phnet_bn_bwd(const float* dy, const float* x, const float* y, cons
     const int nblk = (int)stat_blocks(M, &rpb);
     hipLaunchKernelGGL(channel_partials_kernel<1>, dim3(nblk), dim3(NT), 2 * NT * sizeof(f32x4), st,
                        x, dy, y, save_mean, save_invstd, partial, (long)M, C, rpb, relu);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(NT), 0, st, partial, nblk, (long)M, C,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_NT), 0, st, partial, nblk, (long)M, C,
                        dgamma, dbeta, c1, c2, param_accumulate);
     const long total4 = M * C / 4;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)ceil_div64(total4, NT)), dim3(NT), 0, st,
@@ -477,7 +493,7 @@ PHNET_API int phnet_bn_bwd_reduce(const float* dy, const float* x, const float* 
     const int nblk = (int)stat_blocks(M, &rpb);
     hipLaunchKernelGGL(channel_partials_kernel<1>, dim3(nblk), dim3(NT), 2 * NT * sizeof(f32x4), st,
                        x, dy, y, mean, invstd, partial, (long)M, C, rpb, relu);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(NT), 0, st, partial, nblk, (long)M, C,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_NT), 0, st, partial, nblk, (long)M, C,
                        sums, sums + C, c1_scratch, c2_scratch, 0);
     return phnet_launch_status();
 }

@@ -47,17 +47,19 @@ def main():
     side = torch.cuda.Stream()
     rows = []
     for (sym, shape), recs in groups.items():
+        reps = max(1, 12 // len(recs))                 # at least a dozen launches per replay: a one-kernel graph times the replay, not the kernel
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=side):
-            for rec in recs:
-                rec[5]()
+            for _ in range(reps):
+                for rec in recs:
+                    rec[5]()
         g.replay(); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(5):
             g.replay()
         e1.record(); torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) / 5 * 1e3
+        us = e0.elapsed_time(e1) / 5 / reps * 1e3
         fl = sum(r[2] for r in recs)
         rows.append((us, len(recs), sym, shape, recs[0][1], fl))
     rows.sort(reverse=True)
