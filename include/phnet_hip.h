@@ -191,6 +191,12 @@ int phnet_dwconv3x3_wgrad(const float* dy, const float* x, float* dw, float* db,
 int phnet_lane_assign(const float* pred, const float* tgt, int32_t N, int32_t L, int32_t S,
                       float img_w, float img_h, int64_t* rows_by_col, int64_t* rows_sorted,
                       int32_t* n_valid, float* cost, void* stream);
+/* One-to-many assignment: libs/utils/dynamic_assign.py:292-357 `assignOne2Many` (focal-cost alpha 0.5; label j wants
+ * k_j = max(1, int(sum of its 4 largest line IoUs)) anchors; rounds of the exact matching, each keeps the pairs at the
+ * positions whose k is still positive and retires their anchors) in one launch.  rows / cols [16] i64 (anchor, label row),
+ * the reference's pair order, -1 padded; n_pairs (optional) i32. */
+int phnet_lane_assign_one2many(const float* pred, const float* tgt, int32_t N, int32_t L, int32_t S,
+                               float img_w, float img_h, int64_t* rows, int64_t* cols, int32_t* n_pairs, void* stream);
 
 /* ---- fused per-frame criterion: replaces Criterion4OL.loss4OneStep (libs/utils/loss4OLV3.py:34-82,100-123: assignment,
  * focal, smooth-L1, LaneIoU, gate-weighted combination) AND its autograd backward with two launches.

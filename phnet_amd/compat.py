@@ -14,6 +14,8 @@ _MAP = {
     "libs.models.utils.dynamic_head": "phnet_amd.libs.models.utils.dynamic_head",
     "libs.models.utils.transformer": "phnet_amd.libs.models.utils.transformer",
     "libs.utils.loss4OLV3": "phnet_amd.libs.utils.loss4OLV3",
+    "libs.utils.loss4OL": "phnet_amd.libs.utils.loss4OL",
+    "libs.utils.loss4OLV2": "phnet_amd.libs.utils.loss4OLV2",
     "libs.utils.lane": "phnet_amd.libs.utils.lane",
     "libs.ops": "phnet_amd.libs.ops",
     "libs.ops.nms": "phnet_amd.libs.ops.nms",

@@ -21,6 +21,14 @@ __global__ __launch_bounds__(NT) void lane_assign_kernel(
     lane_assign_block(pred, tgt, N, L, S, img_w, img_h, rows_by_col, rows_sorted, n_valid_out, cost_out, cost);
 }
 
+__global__ __launch_bounds__(NT) void lane_assign_many_kernel(
+    const float* __restrict__ pred, const float* __restrict__ tgt, int N, int L, int S, float img_w, float img_h,
+    int64_t* __restrict__ rows, int64_t* __restrict__ cols, int32_t* __restrict__ n_pairs)
+{
+    extern __shared__ float cost[];                  // [2][N][MAXL]: cost, clamped IoU
+    lane_assign_block<true>(pred, tgt, N, L, S, img_w, img_h, nullptr, nullptr, nullptr, nullptr, cost, 0.5f, rows, cols, n_pairs);
+}
+
 }  // namespace
 // pred [N][6+S] predictions of one head/stage, tgt [L][6+S] label rows (col 1 == 1 marks a valid lane; L <= 4,
 // N <= 256, S <= 250).  rows_by_col [L] int64: matched anchor of label j or -1; rows_sorted [L] int64: the matched
@@ -35,5 +43,19 @@ PHNET_API int phnet_lane_assign(const float* pred, const float* tgt, int32_t N, 
     if (!pred || !tgt || !rows_by_col || !rows_sorted) return PHNET_ERR_ARG;
     hipLaunchKernelGGL(lane_assign_kernel, dim3(1), dim3(NT), (size_t)N * MAXL * sizeof(float), (hipStream_t)stream,
                        pred, tgt, N, L, S, img_w, img_h, rows_by_col, rows_sorted, n_valid, cost);
+    return phnet_launch_status();
+}
+
+// One-to-many assignment, replaces libs/utils/dynamic_assign.py:292-357 `assignOne2Many` (its loop of
+// `C.cpu(); scipy.optimize.linear_sum_assignment(C)` rounds) in one single-workgroup launch.  pred / tgt as phnet_lane_assign.
+// rows / cols [16] int64: the (anchor, label row) pairs in the reference's order (round by round, each round ascending by
+// anchor), padded with -1; n_pairs (optional) their number.
+PHNET_API int phnet_lane_assign_one2many(const float* pred, const float* tgt, int32_t N, int32_t L, int32_t S,
+                                         float img_w, float img_h, int64_t* rows, int64_t* cols, int32_t* n_pairs, void* stream)
+{
+    if (N < 1 || N > NT || L < 1 || L > MAXL || S < 1 || S > 250) return PHNET_ERR_ARG;
+    if (!pred || !tgt || !rows || !cols) return PHNET_ERR_ARG;
+    hipLaunchKernelGGL(lane_assign_many_kernel, dim3(1), dim3(NT), (size_t)2 * N * MAXL * sizeof(float), (hipStream_t)stream,
+                       pred, tgt, N, L, S, img_w, img_h, rows, cols, n_pairs);
     return phnet_launch_status();
 }

@@ -15,17 +15,28 @@ __device__ __forceinline__ float block_max(float v, float* red) {
     return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
+// MANY = false: the one-to-one assignment of `assign` (dynamic_assign.py:128-190; focal_alpha 0.25).
+// MANY = true: `assignOne2Many` (dynamic_assign.py:292-357; focal_alpha 0.5): label j wants k_j = max(1, int(sum of its 4 largest
+// line IoUs)) anchors; rounds of the exact matching over ALL valid labels, each round keeps the pairs whose POSITION p in the
+// row-sorted pair list has k_p > 0 (as shipped: the per-label mask indexes the pair list, :351), retires their rows, decrements
+// the positive k's.  many_rows / many_cols [MAXL*MAXL] (-1 padded; cols = original label rows), many_n = number of pairs.
+template <bool MANY = false>
 __device__ __forceinline__ void lane_assign_block(
     const float* __restrict__ pred, const float* __restrict__ tgt, int N, int L, int S, float img_w, float img_h,
     int64_t* __restrict__ rows_by_col, int64_t* __restrict__ rows_sorted, int32_t* __restrict__ n_valid_out,
-    float* __restrict__ cost_out, float* cost /* LDS [N][MAXL] */)
+    float* __restrict__ cost_out, float* cost /* LDS [N][MAXL] (MANY: [2][N][MAXL], the second half holds the IoUs) */,
+    float focal_alpha = 0.25f, int64_t* __restrict__ many_rows = nullptr, int64_t* __restrict__ many_cols = nullptr,
+    int32_t* __restrict__ many_n = nullptr)
 {
     __shared__ float t_x[MAXL][256];                 // target xs (S <= 250)
     __shared__ float t_len[MAXL], red[4];
     __shared__ int t_valid[MAXL], top_rows[MAXL][MAXL], best_combo;
     __shared__ float combo_cost[NT];
+    __shared__ unsigned char gone[NT];               // MANY: rows retired by earlier rounds
+    __shared__ int ks[MAXL], comp[MAXL], many_count, more;
     const int tid = threadIdx.x;
     const int W = 6 + S;
+    gone[tid] = 0;
 
     if (tid < MAXL) {
         t_valid[tid] = (tid < L) && (tgt[tid * W + 1] == 1.0f);
@@ -48,8 +59,8 @@ __device__ __forceinline__ void lane_assign_block(
         const float* p = pred + (size_t)tid * W;
         // focal cost of the positive class (focal_cost: alpha .25, gamma 2, eps 1e-12), label column 1
         const float pr = 1.0f / (1.0f + expf(-p[1]));
-        const float negc = -logf(1.0f - pr + 1e-12f) * 0.75f * (pr * pr);
-        const float posc = -logf(pr + 1e-12f) * 0.25f * ((1.0f - pr) * (1.0f - pr));
+        const float negc = -logf(1.0f - pr + 1e-12f) * (1.0f - focal_alpha) * (pr * pr);
+        const float posc = -logf(pr + 1e-12f) * focal_alpha * ((1.0f - pr) * (1.0f - pr));
         cls = posc - negc;
         const float psy = p[2] * (img_h - 1.0f), psx = p[3] * (img_w - 1.0f), pth = p[4];
         // one pass over the anchor's S x-columns for all label columns at once (each x is read once, as a float2: the row
@@ -103,11 +114,57 @@ __device__ __forceinline__ void lane_assign_block(
                 c = -(prod * prod) * 3.0f + cls - iou[j];
             }
             cost[tid * MAXL + j] = c;
+            if (MANY) cost[(N + tid) * MAXL + j] = (j < L && t_valid[j]) ? fmaxf(iou[j], 0.f) : -1.f;
             if (cost_out && j < L) cost_out[(size_t)tid * L + j] = c;
         }
     }
     __syncthreads();
 
+    if (MANY) {
+        // k_j per valid label (compact order = ascending j): the 4 largest clamped IoUs of the column, summed in descending order
+        const int j = tid >> 6, lane = tid & 63;
+        if (j < MAXL) {
+            const bool valid = j < L && t_valid[j];
+            float sum = 0.f;
+            int taken[MAXL];
+            for (int r = 0; r < MAXL; ++r) {
+                float bv = -INFINITY; int bi = 0x7fffffff;
+                if (valid)
+                    for (int i = lane; i < N; i += 64) {
+                        bool tk = false;
+                        for (int q = 0; q < r; ++q) tk |= (taken[q] == i);
+                        const float v = cost[(N + i) * MAXL + j];
+                        if (!tk && (v > bv || (v == bv && i < bi))) { bv = v; bi = i; }
+                    }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    const float ov = __shfl_xor(bv, off, 64);
+                    const int oi = __shfl_xor(bi, off, 64);
+                    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+                }
+                taken[r] = bi;
+                if (valid && bi != 0x7fffffff) sum += bv;
+            }
+            if (lane == 0) {
+                const int k = (int)sum;
+                ks[j] = valid ? (k < 1 ? 1 : k) : 0;
+            }
+        }
+        if (tid == 0) many_count = 0;
+        __syncthreads();
+        if (tid == 0) {
+            int c = 0;
+            for (int j = 0; j < MAXL; ++j) { comp[j] = c; c += (j < L && t_valid[j]); }
+            // ks in COMPACT order (the reference filters the valid labels first)
+            int kc[MAXL] = {0, 0, 0, 0};
+            for (int j = 0; j < MAXL; ++j) if (j < L && t_valid[j]) kc[comp[j]] = ks[j];
+            for (int j = 0; j < MAXL; ++j) ks[j] = kc[j];
+            more = (kc[0] + kc[1] + kc[2] + kc[3]) > 0;
+        }
+        __syncthreads();
+    }
+    for (int round = 0; round < (MANY ? MAXL + 1 : 1); ++round) {
+    if (MANY && !more) break;
     // ---- the MAXL cheapest rows of every valid column (wave j <-> column j) -----------------------------------
     {
         const int j = tid >> 6, lane = tid & 63;
@@ -117,7 +174,7 @@ __device__ __forceinline__ void lane_assign_block(
                 float bv = INFINITY; int bi = 0x7fffffff;
                 if (valid)
                     for (int i = lane; i < N; i += 64) {
-                        bool taken = false;
+                        bool taken = gone[i] != 0;
                         for (int q = 0; q < r; ++q) taken |= (top_rows[j][q] == i);
                         const float c = cost[i * MAXL + j];
                         if (!taken && (c < bv || (c == bv && i < bi))) { bv = c; bi = i; }
@@ -174,7 +231,7 @@ __device__ __forceinline__ void lane_assign_block(
         for (int j = 0; j < MAXL; ++j) {
             const bool valid = j < L && t_valid[j];
             rows[j] = (valid && best_combo != 0x7fffffff) ? top_rows[j][(best_combo >> (2 * j)) & 3] : -1;
-            if (j < L) rows_by_col[j] = rows[j];
+            if (j < L && rows_by_col) rows_by_col[j] = rows[j];
             nv += rows[j] >= 0;
         }
         // ascending valid rows first (prior-index order, as scipy returns them), then -1
@@ -183,8 +240,35 @@ __device__ __forceinline__ void lane_assign_block(
                 const bool swap = (rows[b] >= 0) && (rows[a] < 0 || rows[b] < rows[a]);
                 if (swap) { const int t = rows[a]; rows[a] = rows[b]; rows[b] = t; }
             }
-        for (int j = 0; j < L; ++j) rows_sorted[j] = rows[j];
-        if (n_valid_out) *n_valid_out = nv;
+        if (!MANY) {
+            for (int j = 0; j < L; ++j) rows_sorted[j] = rows[j];
+            if (n_valid_out) *n_valid_out = nv;
+        } else {
+            // pairs in row-sorted order: position p carries (row, label); keep where k_p > 0, retire the kept rows
+            int lab[MAXL];
+            for (int p_ = 0; p_ < MAXL; ++p_) {
+                lab[p_] = -1;
+                if (rows[p_] < 0) continue;
+                for (int j = 0; j < MAXL; ++j)
+                    if (j < L && t_valid[j] && best_combo != 0x7fffffff && top_rows[j][(best_combo >> (2 * j)) & 3] == rows[p_]) lab[p_] = j;
+            }
+            for (int p_ = 0; p_ < MAXL; ++p_) {
+                if (rows[p_] < 0 || ks[p_] <= 0) continue;
+                many_rows[many_count] = rows[p_];
+                many_cols[many_count] = lab[p_];
+                ++many_count;
+                gone[rows[p_]] = 1;
+            }
+            int any = 0;
+            for (int j = 0; j < MAXL; ++j) { if (ks[j] > 0) --ks[j]; any += ks[j]; }
+            more = any > 0 && nv > 0;
+        }
+    }
+    __syncthreads();
+    }   // rounds
+    if (MANY && tid == 0) {
+        for (int i = many_count; i < MAXL * MAXL; ++i) { many_rows[i] = -1; many_cols[i] = -1; }
+        if (many_n) *many_n = many_count;
     }
 }
 

@@ -520,6 +520,19 @@ def lane_assign(pred, tgt, img_w: int, img_h: int, want_cost: bool = False):
     return (rows, srt, nv, cost) if want_cost else (rows, srt, nv)
 
 
+def lane_assign_one2many(pred, tgt, img_w: int, img_h: int):
+    """pred [N,6+S], tgt [L<=4,6+S] (all label rows, valid flag in column 1) -> (rows i64[16], cols i64[16], n i32[]): the
+    (anchor, label row) pairs of dynamic_assign.assignOne2Many in the reference's order, -1 padded; no host sync."""
+    _req(pred, name="pred"); _req(tgt, name="tgt")
+    n, w = pred.shape
+    rows = torch.empty(16, dtype=torch.int64, device=pred.device)
+    cols = torch.empty(16, dtype=torch.int64, device=pred.device)
+    cnt = torch.empty((), dtype=torch.int32, device=pred.device)
+    check(lib().phnet_lane_assign_one2many(_ptr(pred), _ptr(tgt), n, tgt.shape[0], w - 6, float(img_w), float(img_h), _ptr(rows), _ptr(cols),
+                                           _ptr(cnt), _stream()), "phnet_lane_assign_one2many")
+    return rows, cols, cnt
+
+
 def frame_loss(preds, gates, tgt, img_w, img_h, cls_w, reg_w, iou_w, liou_hw, liou_h, liou_w):
     """preds: 6 x [N,6+S] (branch A stages 0..2, branch B stages 0..2), gates: 3 x [N], tgt [L,6+S].
     Returns (loss [1], dpred [6,N,6+S], dgate [3,N], rows_by_col [6,L] i64, rows_sorted [6,L] i64)."""

@@ -861,3 +861,49 @@ def test_ten_frame_clip_exercises_memory_fifo_vs_oracle():
     assert agree >= 27, agree                      # label assignment: identical on (almost) every frame x stage
     assert rec["matched"][0][0].tolist() == col["positives"][0][0].tolist()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+
+
+# ------------------------------------------------------------------------------------------------ criterion variants
+def _criterion_cases(g):
+    a, b = _gold("tiny_ragged_r18_64x160.npz"), _gold("tiny_r18_64x160.npz")
+    la, lb = synth.make_targets(g, 4, counts=(0, 4, 1, 2)), synth.make_targets(g, 3)
+    out = []
+    for src, lanes, T in ((a, la, 4), (b, lb, 3)):
+        for t in range(T):
+            out.append((src["train_fir"][t], src["train_sec"][t], src["train_gate"][t], lanes[t:t + 1]))
+    return out
+
+
+@pytest.mark.parametrize("tag", ["v1", "v2"])
+def test_criterion_variants_vs_reference_fixture(tag):
+    """libs.utils.loss4OL (trainOLV2/V3.py) and libs.utils.loss4OLV2 (one-to-many assignment) on the device against what the
+    reference's own classes produced on the same head outputs (tests/golden/make_goldens_criteria.py): matched anchors exact
+    (the one-to-many pairs in the reference's round order), loss 1e-5 relative, every input gradient 1e-4."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from phnet_amd.config import make_cfg
+    g = O.Geometry(img_h=64, img_w=160, arch="resnet18")
+    cfg = make_cfg(img_h=g.img_h, img_w=g.img_w, arch=g.arch)
+    if tag == "v1":
+        from phnet_amd.libs.utils.loss4OL import Criterion4OL
+    else:
+        from phnet_amd.libs.utils.loss4OLV2 import Criterion4OL
+    crit = Criterion4OL(cfg).cuda()
+    gold = _gold("criterion_variants_tiny.npz")
+    for i, (fir, sec, gate, gt) in enumerate(_criterion_cases(g)):
+        f = [torch.from_numpy(fir[s]).unsqueeze(0).cuda().requires_grad_() for s in range(3)]
+        s_ = [torch.from_numpy(sec[s]).unsqueeze(0).cuda().requires_grad_() for s in range(3)]
+        d = [torch.from_numpy(gate[s]).view(1, -1, 1).cuda().requires_grad_() for s in range(3)]
+        res = crit({"predictions_fir": f, "predictions_sec": s_}, gt.cuda(), d)
+        matched, loss = res[0], res[1]
+        loss.backward()
+        assert abs(float(loss) - gold[f"{tag}_loss"][i]) <= 1e-5 * abs(gold[f"{tag}_loss"][i]), (i, float(loss), gold[f"{tag}_loss"][i])
+        for st in range(3):
+            got = [r for r in matched[st].cpu().tolist() if r >= 0]
+            assert got == [r for r in gold[f"{tag}_matched"][i, st].tolist() if r >= 0], (i, st, got)
+        _close(torch.stack([x.grad[0] for x in f]), gold[f"{tag}_dfir"][i], 1e-4, f"dfir {i}")
+        _close(torch.stack([x.grad[0] for x in s_]), gold[f"{tag}_dsec"][i], 1e-4, f"dsec {i}")
+        _close(torch.stack([x.grad[0, :, 0] for x in d]), gold[f"{tag}_dgate"][i], 1e-4, f"dgate {i}")
+        if tag == "v2":
+            k = int((matched[-1] >= 0).sum())
+            assert res[2].shape == (1, 16, 42) and k == int((gold["v2_matched"][i, 2] >= 0).sum())
