@@ -84,11 +84,26 @@ __device__ __forceinline__ void finalize_column_sums(const float* __restrict__ p
     const int cl = threadIdx.x % FIN_CH, g = threadIdx.x / FIN_CH;
     const int c = blockIdx.x * FIN_CH + cl;
     double a = 0.0, b = 0.0;
-    if (c < C)
-        for (int r = g; r < nblk; r += FIN_G) {
-            a += (double)partial[(size_t)r * 2 * C + c];
-            b += (double)partial[(size_t)r * 2 * C + C + c];
+    if (c < C) {
+        // four rows per trip, all eight loads issued before the first add: the loop is a chain of memory latencies otherwise
+        // (rows beyond nblk re-read row g and are weighted 0: branch-free)
+        for (int r = g; r < nblk; r += 4 * FIN_G) {
+            float v[4], w[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int rr = r + u * FIN_G;
+                const size_t o = (size_t)(rr < nblk ? rr : g) * 2 * C + c;
+                v[u] = partial[o];
+                w[u] = partial[o + C];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool in = r + u * FIN_G < nblk;
+                a += in ? (double)v[u] : 0.0;
+                b += in ? (double)w[u] : 0.0;
+            }
         }
+    }
     red[threadIdx.x] = a;
     red[FIN_NT + threadIdx.x] = b;
     __syncthreads();
