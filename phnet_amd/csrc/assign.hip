@@ -12,21 +12,21 @@ namespace {
 
 using namespace phassign;
 
-__global__ __launch_bounds__(NT) void lane_assign_kernel(
+__global__ __launch_bounds__(4 * NT) void lane_assign_kernel(
     const float* __restrict__ pred, const float* __restrict__ tgt, int N, int L, int S, float img_w, float img_h,
     int64_t* __restrict__ rows_by_col, int64_t* __restrict__ rows_sorted, int32_t* __restrict__ n_valid_out,
     float* __restrict__ cost_out)
 {
     extern __shared__ float cost[];                  // [N][MAXL]
-    lane_assign_block(pred, tgt, N, L, S, img_w, img_h, rows_by_col, rows_sorted, n_valid_out, cost_out, cost);
+    lane_assign_block<false, 4>(pred, tgt, N, L, S, img_w, img_h, rows_by_col, rows_sorted, n_valid_out, cost_out, cost);
 }
 
-__global__ __launch_bounds__(NT) void lane_assign_many_kernel(
+__global__ __launch_bounds__(4 * NT) void lane_assign_many_kernel(
     const float* __restrict__ pred, const float* __restrict__ tgt, int N, int L, int S, float img_w, float img_h,
     int64_t* __restrict__ rows, int64_t* __restrict__ cols, int32_t* __restrict__ n_pairs)
 {
     extern __shared__ float cost[];                  // [2][N][MAXL]: cost, clamped IoU
-    lane_assign_block<true>(pred, tgt, N, L, S, img_w, img_h, nullptr, nullptr, nullptr, nullptr, cost, 0.5f, rows, cols, n_pairs);
+    lane_assign_block<true, 4>(pred, tgt, N, L, S, img_w, img_h, nullptr, nullptr, nullptr, nullptr, cost, 0.5f, rows, cols, n_pairs);
 }
 
 }  // namespace
@@ -41,7 +41,7 @@ PHNET_API int phnet_lane_assign(const float* pred, const float* tgt, int32_t N, 
     if (N < 1 || N > NT || L < 0 || L > MAXL || S < 1 || S > 250) return PHNET_ERR_ARG;
     if (L == 0) return PHNET_OK;
     if (!pred || !tgt || !rows_by_col || !rows_sorted) return PHNET_ERR_ARG;
-    hipLaunchKernelGGL(lane_assign_kernel, dim3(1), dim3(NT), (size_t)N * MAXL * sizeof(float), (hipStream_t)stream,
+    hipLaunchKernelGGL(lane_assign_kernel, dim3(1), dim3(4 * NT), (size_t)N * MAXL * sizeof(float), (hipStream_t)stream,
                        pred, tgt, N, L, S, img_w, img_h, rows_by_col, rows_sorted, n_valid, cost);
     return phnet_launch_status();
 }
@@ -55,7 +55,7 @@ PHNET_API int phnet_lane_assign_one2many(const float* pred, const float* tgt, in
 {
     if (N < 1 || N > NT || L < 1 || L > MAXL || S < 1 || S > 250) return PHNET_ERR_ARG;
     if (!pred || !tgt || !rows || !cols) return PHNET_ERR_ARG;
-    hipLaunchKernelGGL(lane_assign_many_kernel, dim3(1), dim3(NT), (size_t)2 * N * MAXL * sizeof(float), (hipStream_t)stream,
+    hipLaunchKernelGGL(lane_assign_many_kernel, dim3(1), dim3(4 * NT), (size_t)2 * N * MAXL * sizeof(float), (hipStream_t)stream,
                        pred, tgt, N, L, S, img_w, img_h, rows, cols, n_pairs);
     return phnet_launch_status();
 }

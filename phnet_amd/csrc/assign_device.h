@@ -7,20 +7,27 @@ namespace phassign {
 constexpr int NT = 256;
 constexpr int MAXL = 4;
 
+template <int WAVES = 4>
 __device__ __forceinline__ float block_max(float v, float* red) {
     v = wave_max(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
-    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float m = red[0];
+#pragma unroll
+    for (int i = 1; i < WAVES; ++i) m = fmaxf(m, red[i]);
+    return m;
 }
 
+// QUAD = 4: the workgroup has 4 x NT threads and the cost phase gives every (anchor, label) pair its own thread (with one thread
+// per anchor the 4 waves of the single workgroup sit alone on their SIMDs and the 4 S-long accumulation chains of a thread run at
+// the latency of dependent VALU issue: 14 of the kernel's 23 us); the matching phases use the first NT threads as before.
 // MANY = false: the one-to-one assignment of `assign` (dynamic_assign.py:128-190; focal_alpha 0.25).
 // MANY = true: `assignOne2Many` (dynamic_assign.py:292-357; focal_alpha 0.5): label j wants k_j = max(1, int(sum of its 4 largest
 // line IoUs)) anchors; rounds of the exact matching over ALL valid labels, each round keeps the pairs whose POSITION p in the
 // row-sorted pair list has k_p > 0 (as shipped: the per-label mask indexes the pair list, :351), retires their rows, decrements
 // the positive k's.  many_rows / many_cols [MAXL*MAXL] (-1 padded; cols = original label rows), many_n = number of pairs.
-template <bool MANY = false>
+template <bool MANY = false, int QUAD = 1>
 __device__ __forceinline__ void lane_assign_block(
     const float* __restrict__ pred, const float* __restrict__ tgt, int N, int L, int S, float img_w, float img_h,
     int64_t* __restrict__ rows_by_col, int64_t* __restrict__ rows_sorted, int32_t* __restrict__ n_valid_out,
@@ -29,20 +36,20 @@ __device__ __forceinline__ void lane_assign_block(
     int32_t* __restrict__ many_n = nullptr)
 {
     __shared__ float t_x[MAXL][256];                 // target xs (S <= 250)
-    __shared__ float t_len[MAXL], red[4];
+    __shared__ float t_len[MAXL], red[4 * QUAD];
     __shared__ int t_valid[MAXL], top_rows[MAXL][MAXL], best_combo;
     __shared__ float combo_cost[NT];
     __shared__ unsigned char gone[NT];               // MANY: rows retired by earlier rounds
     __shared__ int ks[MAXL], comp[MAXL], many_count, more;
     const int tid = threadIdx.x;
     const int W = 6 + S;
-    gone[tid] = 0;
+    if (tid < NT) gone[tid] = 0;
 
     if (tid < MAXL) {
         t_valid[tid] = (tid < L) && (tgt[tid * W + 1] == 1.0f);
         t_len[tid] = 0.f;
     }
-    for (int i = tid; i < L * S; i += NT) t_x[i / S][i % S] = tgt[(i / S) * W + 6 + (i % S)];
+    for (int i = tid; i < L * S; i += NT * QUAD) t_x[i / S][i % S] = tgt[(i / S) * W + 6 + (i % S)];
     __syncthreads();
     if (tid < L) {
         int n = 0;
@@ -51,6 +58,72 @@ __device__ __forceinline__ void lane_assign_block(
     }
     __syncthreads();
 
+    if constexpr (QUAD == 4) {
+        // ---- one thread per (anchor, label): the label index is wave-uniform ------------------------------------------
+        const int a = tid & (NT - 1), jq = tid / NT;
+        const bool arow = a < N, on = arow && jq < L && t_valid[jq];
+        const float* p = pred + (size_t)(arow ? a : 0) * W;
+        float cls = 0.f, dist = 0.f, start = 0.f, theta = 0.f, iou = 0.f;
+        float mx_d = -INFINITY, mx_s = -INFINITY, mx_t = -INFINITY;
+        if (arow) {
+            const float pr = 1.0f / (1.0f + expf(-p[1]));
+            const float negc = -logf(1.0f - pr + 1e-12f) * (1.0f - focal_alpha) * (pr * pr);
+            const float posc = -logf(pr + 1e-12f) * focal_alpha * ((1.0f - pr) * (1.0f - pr));
+            cls = posc - negc;
+        }
+        if (on) {
+            float d = 0.f, ovr = 0.f, uni = 0.f;
+            const float* tx = t_x[jq];
+            auto term = [&](int k, float xr) {
+                const float x = xr * (img_w - 1.0f), t = tx[k];
+                const bool ok = !(t < 0.f) && !(t >= img_w);
+                d += ok ? fabsf(t - x) : 0.f;
+                ovr += ok ? fminf(x + 15.f, t + 15.f) - fmaxf(x - 15.f, t - 15.f) : 0.f;
+                uni += ok ? fmaxf(x + 15.f, t + 15.f) - fminf(x - 15.f, t - 15.f) : 0.f;
+            };
+            int k = 0;
+            if ((W & 1) == 0) {
+                for (; k + 1 < S; k += 16) {
+                    float2 buf[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int kk = k + 2 * u;
+                        buf[u] = *reinterpret_cast<const float2*>(p + 6 + (kk + 1 < S ? kk : 0));
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int kk = k + 2 * u;
+                        if (kk + 1 < S) { term(kk, buf[u].x); term(kk + 1, buf[u].y); }
+                    }
+                }
+                k = S & ~1;
+            }
+            for (; k < S; ++k) term(k, p[6 + k]);
+            dist = d / (t_len[jq] + 1e-9f);
+            iou = ovr / (uni + 1e-9f);
+            const float* tr = tgt + (size_t)jq * W;
+            const float dy = p[2] * (img_h - 1.0f) - tr[2] * (img_h - 1.0f), dx = p[3] * (img_w - 1.0f) - tr[3] * (img_w - 1.0f);
+            start = sqrtf(dy * dy + dx * dx);
+            theta = fabsf(p[4] - tr[4]) * 180.f;
+            mx_d = dist; mx_s = start; mx_t = theta;
+        }
+        mx_d = block_max<16>(mx_d, red);
+        mx_s = block_max<16>(mx_s, red);
+        mx_t = block_max<16>(mx_t, red);
+        if (arow) {
+            float c = INFINITY;
+            if (on) {
+                const float a_ = 1.0f - dist / (mx_d + 1e-4f);
+                const float b_ = 1.0f - start / (mx_s + 1e-4f);
+                const float t_ = 1.0f - theta / (mx_t + 1e-4f);
+                const float prod = a_ * b_ * t_;
+                c = -(prod * prod) * 3.0f + cls - iou;
+            }
+            cost[a * MAXL + jq] = c;
+            if (MANY) cost[(N + a) * MAXL + jq] = on ? fmaxf(iou, 0.f) : -1.f;
+            if (cost_out && jq < L) cost_out[(size_t)a * L + jq] = c;
+        }
+    } else {
     // ---- per-anchor raw terms ------------------------------------------------------------------------------
     float dist[MAXL], start[MAXL], theta[MAXL], iou[MAXL], cls = 0.f;
     float mx_d = -INFINITY, mx_s = -INFINITY, mx_t = -INFINITY;
@@ -68,23 +141,40 @@ __device__ __forceinline__ void lane_assign_block(
         float d[MAXL], ovr[MAXL], uni[MAXL];
 #pragma unroll
         for (int j = 0; j < MAXL; ++j) d[j] = ovr[j] = uni[j] = 0.f;
+        // branch-free: a branch on the freshly read label value (or on the LDS validity flag) makes every one of the 4 S trips wait
+        // for its LDS read - the loop then is a chain of ~150 LDS latencies, most of this kernel's time; adding 0 leaves a sum as it is
+        bool col_on[MAXL];
+#pragma unroll
+        for (int j = 0; j < MAXL; ++j) col_on[j] = j < L && t_valid[j];
         auto term = [&](int k, float xr) {
             const float x = xr * (img_w - 1.0f);
 #pragma unroll
             for (int j = 0; j < MAXL; ++j) {
                 const float t = t_x[j][k];
-                if (j >= L || !t_valid[j] || (t < 0.f) || (t >= img_w)) continue;
-                d[j] += fabsf(t - x);
-                ovr[j] += fminf(x + 15.f, t + 15.f) - fmaxf(x - 15.f, t - 15.f);
-                uni[j] += fmaxf(x + 15.f, t + 15.f) - fminf(x - 15.f, t - 15.f);
+                const bool ok = col_on[j] && !(t < 0.f) && !(t >= img_w);
+                d[j] += ok ? fabsf(t - x) : 0.f;
+                ovr[j] += ok ? fminf(x + 15.f, t + 15.f) - fmaxf(x - 15.f, t - 15.f) : 0.f;
+                uni[j] += ok ? fmaxf(x + 15.f, t + 15.f) - fminf(x - 15.f, t - 15.f) : 0.f;
             }
         };
         int k = 0;
         if ((W & 1) == 0)
-            for (; k + 1 < S; k += 2) {
-                const float2 xx = *reinterpret_cast<const float2*>(p + 6 + k);
-                term(k, xx.x); term(k + 1, xx.y);
+            // 16 columns per trip, their 8 loads issued together (clamped addresses, branch-free): with one load per trip the loop
+            // was a chain of S/2 memory latencies (18 x ~0.5 us at S = 36 - most of this kernel's 26 us)
+            for (; k + 1 < S; k += 16) {
+                float2 buf[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int kk = k + 2 * u;
+                    buf[u] = *reinterpret_cast<const float2*>(p + 6 + (kk + 1 < S ? kk : 0));
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int kk = k + 2 * u;
+                    if (kk + 1 < S) { term(kk, buf[u].x); term(kk + 1, buf[u].y); }
+                }
             }
+        k = ((W & 1) == 0) ? (S & ~1) : 0;
         for (; k < S; ++k) term(k, p[6 + k]);
 #pragma unroll
         for (int j = 0; j < MAXL; ++j) {
@@ -117,6 +207,7 @@ __device__ __forceinline__ void lane_assign_block(
             if (MANY) cost[(N + tid) * MAXL + j] = (j < L && t_valid[j]) ? fmaxf(iou[j], 0.f) : -1.f;
             if (cost_out && j < L) cost_out[(size_t)tid * L + j] = c;
         }
+    }
     }
     __syncthreads();
 
@@ -208,7 +299,7 @@ __device__ __forceinline__ void lane_assign_block(
 #pragma unroll
             for (int q = 0; q < j; ++q) ok = ok && !(rows[q] >= 0 && rows[q] == rows[j]);
         }
-        combo_cost[tid] = ok ? total : INFINITY;
+        if (tid < NT) combo_cost[tid] = ok ? total : INFINITY;
     }
     __syncthreads();
     if (tid < 64) {
