@@ -1,0 +1,143 @@
+"""GPU-box measurement of the SURVEY 8(f) "next" rows (the same bar as the hot path: absolute rate, the roofline that bounds the
+kernel, the CPU oracle timed beside it on the host cores).  Prints ONE JSON object; profiles/r02_next_rows.json keeps a copy.
+  f1  Router4OLV2 family (what testOLV3.py runs): inference clips/s of a 5-frame 320x800 clip, ResNet-18, one hipGraph per clip
+  f2  criterion variants loss4OL / loss4OLV2 (+ one-to-many assignment): per-frame time on the device vs the CPU oracle (scipy)
+  f4  input pre-processing: frames/s and HBM GB/s of the one-launch crop / bicubic resize / normalise kernel"""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np
+import torch
+
+
+def timed(fn, n, sync=True):
+    fn(); torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t) / n
+
+
+def main():
+    dev = torch.device("cuda", 0)
+    out = {"device": torch.cuda.get_device_name(0), "host_threads": min(16, os.cpu_count() or 1)}
+    torch.set_num_threads(out["host_threads"])
+    # ---------------------------------------------------------------- f1: Router4OLV2 inference
+    from oracle import lane_nms as ONMS
+    from oracle import phnet_cpu_v2 as O2
+    from phnet_amd.config import make_cfg_v2
+    from phnet_amd.graphed import GraphedInference
+    from phnet_amd.libs.models.Router4OLV2 import RouterOL as RouterOLV2
+    from tests import synth
+    g = O2.GeometryV2()
+    T = 5
+    model = RouterOLV2(make_cfg_v2()).to(dev).eval()
+    model.load_state_dict(synth.make_state_v2(g), strict=True)
+    clips = [synth.make_clip(g, T, seed=77 + i).to(dev) for i in range(4)]
+    with torch.no_grad():
+        eager = timed(lambda: model.infer_device(clips[0]), 5)
+    gi = GraphedInference(model, clips[0])
+    k = [0]
+
+    def replay():
+        k[0] += 1
+        return gi(clips[k[0] % 4])
+    dt = timed(replay, 40)
+    rows, nums = gi(clips[1])[:2]
+    torch.cuda.synchronize()
+    sd = synth.make_state_v2(g)
+    with torch.no_grad():
+        O2.clip_forward_eval_v2(sd, clips[1].cpu(), g, ONMS.lane_nms)
+        t0 = time.perf_counter()
+        for i in range(3):
+            O2.clip_forward_eval_v2(sd, clips[i].cpu(), g, ONMS.lane_nms)
+        cpu = (time.perf_counter() - t0) / 3
+    out["f1_router4olv2_inference"] = {
+        "workload": "5-frame clip 3x320x800, ResNet-18 + fpnV2 + RouterV2 head + fused decode/NMS (72 offsets), eval, synthetic weights",
+        "clips_per_s_hipgraph": round(1 / dt, 1), "frames_per_s_hipgraph": round(T / dt, 1), "ms_per_clip_hipgraph": round(dt * 1e3, 3),
+        "ms_per_clip_eager": round(eager * 1e3, 3), "kept_lanes_per_frame": nums.cpu().tolist(),
+        "cpu_baseline": {"clips_per_s": round(1 / cpu, 3), "cores": out["host_threads"], "kind": "port",
+                         "sample": "3 clips, oracle/phnet_cpu_v2.py on torch CPU fp32 after one warm-up clip"},
+        "bound": "latency (launch-bound lane head at 240 anchors) + MFMA (trunk); no single dominant kernel"}
+    # ---------------------------------------------------------------- f4: pre-processing
+    from phnet_amd.libs.dataset.openlane.preprocess import ClipPreprocessor
+    pre = ClipPreprocessor(320, 800, device=dev)
+    raw = torch.randint(0, 256, (T, 1280, 1920, 3), dtype=torch.uint8, device=dev)
+    dtp = timed(lambda: pre(raw), 50)
+    src_rows = 1280 - 480
+    bytes_alg = T * (src_rows * 1920 * 3 + 320 * 800 * 3 * 4)
+    from oracle import preprocess_cpu as OP
+    raw_h = raw.cpu().numpy()
+    t0 = time.perf_counter()
+    OP.preprocess_clip(raw_h[:1], 480, 320, 800, (0.485, 0.456, 0.406), (0.229, 0.224, 0.225))
+    cpu_pre = time.perf_counter() - t0
+    out["f4_preprocess"] = {
+        "workload": "5 frames 1280x1920x3 u8 -> crop 480 -> 8-bit bicubic resize -> ToTensor/Normalize -> 5x3x320x800 f32, one launch",
+        "clips_per_s": round(1 / dtp, 1), "frames_per_s": round(T / dtp, 1), "us_per_clip": round(dtp * 1e6, 1),
+        "roofline": {"bound": "hbm", "achieved": round(bytes_alg / dtp / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                     "frac": round(bytes_alg / dtp / 8e12, 4),
+                     "algorithmic_bytes_per_clip": bytes_alg,
+                     "note": "each source byte of the cropped frame read once + each output float written once; the 16-tap gather re-reads "
+                             "come from L2; at 23 MB per clip the launch is too short to approach the HBM rate"},
+        "cpu_baseline_s_per_frame": round(cpu_pre, 3) if cpu_pre > 1e-4 else None}
+    # ---------------------------------------------------------------- f2: criterion variants
+    from oracle import criterion_variants_cpu as OC
+    from oracle import phnet_cpu as O
+    from phnet_amd.config import make_cfg
+    from phnet_amd.libs.utils.loss4OL import Criterion4OL as V1
+    from phnet_amd.libs.utils.loss4OLV2 import Criterion4OL as V2
+    g1 = O.Geometry()
+    cfg = make_cfg()
+    r = np.random.default_rng(0)
+    gt = synth.make_targets(g1, 1)
+    base = O.priors_from_embeddings(O.initial_anchor_embeddings(g1), g1)[0]
+    preds = [(base + torch.from_numpy(r.normal(0, 0.02, base.shape).astype(np.float32))).unsqueeze(0) for _ in range(6)]
+    for p in preds:
+        p[0, :, :2] = torch.from_numpy(r.normal(0, 1, (240, 2)).astype(np.float32))
+        p[0, :, 5] = 0.6
+    gates = [torch.from_numpy(r.uniform(0.5, 0.9, (1, 240, 1)).astype(np.float32)) for _ in range(3)]
+    crit = {}
+    for name, cls, fn in (("loss4OL", V1, OC.frame_loss_v1), ("loss4OLV2", V2, OC.frame_loss_v2)):
+        c = cls(cfg).to(dev)
+        pd = [p.to(dev).requires_grad_() for p in preds]
+        gd = [x.to(dev).requires_grad_() for x in gates]
+        gtd = gt.to(dev)
+
+        def step():
+            res = c({"predictions_fir": pd[:3], "predictions_sec": pd[3:]}, gtd, gd)
+            res[1].backward()
+        dtc = timed(step, 20)
+        # the same forward + backward replayed from a hipGraph (how a captured training step runs it: no host dispatch)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        for t_ in pd + gd:
+            t_.grad = None
+        cg = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(cg):
+            step()
+        dtg = timed(cg.replay, 50)
+        pc = [p.clone().requires_grad_() for p in preds]
+        gc = [x.clone().requires_grad_() for x in gates]
+        t0 = time.perf_counter()
+        for _ in range(5):
+            fn(pc[:3], pc[3:], gc, gt, g1)[1].backward()
+        cpu_c = (time.perf_counter() - t0) / 5
+        crit[name] = {"ms_per_frame_fwd_bwd_hipgraph": round(dtg * 1e3, 3), "ms_per_frame_fwd_bwd_eager": round(dtc * 1e3, 3),
+                      "ms_per_frame_fwd_bwd_cpu_oracle": round(cpu_c * 1e3, 3),
+                      "note": "device: HIP assignment kernel(s) + tensor-op loss under autograd, no host sync; eager = bound by the host's "
+                              "operator dispatch (~450 tiny launches), hipGraph = how a captured training step runs it; bound: launch latency"}
+    out["f2_criterion_variants"] = crit
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
