@@ -298,6 +298,18 @@ int phnet_dyn_bmm_ln_relu_fwd_any(const float* x, const float* w, const float* g
 int phnet_route_lines(const float* gates, const float* a, const float* b, float* out,
                       int32_t S, int32_t M, int32_t W, int32_t hard, void* stream);
 
+/* ---- row-local chain of a pre-norm transformer layer in one launch, forward only (libs/models/utils/transformer.py:275-298
+ * between the attention cores): [v = in @ Wa^T + ba; t = resid + dropout(v)] | t = in;  h = LayerNorm(t; ln1);
+ * [f = dropout(gelu(h @ W1^T + b1)); t += dropout(f @ W2^T + b2); h = LayerNorm(t; ln2)];  [y = h @ Wg^T + bg].
+ * in / resid / t_out / h_out [R][E], y_out [R][NG]; E = 128 (FF 256) or 256 (FF 512); optional parts are NULL.  Dropout sites as
+ * in phnet_dropout_add (same generator, same element indices as the unfused kernels: a recomputation through those sees the
+ * masks drawn here). ---- */
+int phnet_rowchain_fwd(const float* in, const float* resid, const float* Wa, const float* ba, const float* ln1w, const float* ln1b,
+                       const float* W1, const float* b1, const float* W2, const float* b2, const float* ln2w, const float* ln2b,
+                       const float* Wg, const float* bg, float* t_out, float* h_out, float* y_out,
+                       int32_t R, int32_t E, int32_t FF, int32_t NG, float eps,
+                       const uint64_t* rng_state, uint64_t call_a, uint64_t call_f, uint64_t call_3, float drop_p, void* stream);
+
 /* ---- optimizer: one AdamW step (torch.optim.AdamW semantics, libs/utils/optimizer.py:33-35) over flat parameter / gradient /
  * moment arrays; elements [0, n_decay) get decoupled weight decay.  n % 4 == 0.  step: device int64, 1-based, already
  * incremented by the caller for this step.  lr_dev (optional): DEVICE pointer to the learning rate; when non-NULL it

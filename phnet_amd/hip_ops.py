@@ -822,6 +822,39 @@ def route_lines(gates, a, b, hard: bool):
     return out
 
 
+def rowchain_fwd(x, resid=None, wa=None, ba=None, ln1=None, ffn=None, ln2=None, wg=None, bg=None, eps: float = 1e-5,
+                 rng_a=None, rng_f=None, rng_3=None, want_t: bool = True, want_h: bool = False):
+    """Row-local chain of a transformer layer in one launch (csrc/rowchain.hip), forward only.  x [R,E]; wa / ba: out-projection
+    (then t = resid + dropout_a(.)); ln1 = (w, b); ffn = (W1, b1, W2, b2) with ln2 = (w, b); wg / bg: next projection.
+    rng_*: DropoutStream.site tuples (None = no dropout at that site; all sites share one probability).  -> (t, h, y), each None
+    when not produced."""
+    _req(x, name="x")
+    r, e = x.shape
+    dev = x.device
+    t = torch.empty((r, e), dtype=torch.float32, device=dev) if want_t else None
+    h = torch.empty((r, e), dtype=torch.float32, device=dev) if want_h else None
+    ng = wg.shape[0] if wg is not None else 0
+    y = torch.empty((r, ng), dtype=torch.float32, device=dev) if wg is not None else None
+    w1 = b1 = w2 = b2 = None
+    ff = 0
+    if ffn is not None:
+        w1, b1, w2, b2 = ffn
+        ff = w1.shape[0]
+    sites = [s for s in (rng_a, rng_f, rng_3) if s is not None]
+    state, p = (sites[0][0], sites[0][2]) if sites else (None, 0.0)
+
+    def call(rng, width):
+        return 0 if rng is None else _rng_args(rng, width)[1]
+    for tns in (resid, wa, ba, w1, b1, w2, b2, wg, bg) + tuple(ln1) + (tuple(ln2) if ln2 is not None else ()):
+        if tns is not None:
+            _req(tns, name="rowchain operand")
+    check(lib().phnet_rowchain_fwd(_ptr(x), _ptr(resid), _ptr(wa), _ptr(ba), _ptr(ln1[0]), _ptr(ln1[1]), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2),
+                                   _ptr(ln2[0]) if ln2 is not None else None, _ptr(ln2[1]) if ln2 is not None else None, _ptr(wg), _ptr(bg),
+                                   _ptr(t), _ptr(h), _ptr(y), r, e, ff, ng, float(eps), _ptr(state), call(rng_a, e), call(rng_f, ff), call(rng_3, e),
+                                   float(p), _stream()), "phnet_rowchain_fwd")
+    return t, h, y
+
+
 DEFAULT_MMA = "bf16x3"
 
 

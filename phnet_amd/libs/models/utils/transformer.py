@@ -65,11 +65,61 @@ class TransformerDecoder(nn.Module):
         self.norm = copy.deepcopy(norm)
         self.return_intermediate = return_intermediate
 
+    fuse_row_chains = True      # no-autograd forward: the row-local chains between the attention cores as single launches
+
+    def _forward_row_chains(self, x: torch.Tensor, mem: torch.Tensor, memory_key_valid, batch: int) -> torch.Tensor:
+        """The same decoder with every row-local chain of a layer in one launch (csrc/rowchain.hip): per layer
+        [LayerNorm + q|k|v projection] -> self-attention core -> [out-projection + residual/dropout + LayerNorm + q projection]
+        -> cross-attention core -> [out-projection + residual/dropout + LayerNorm + feed-forward + residual/dropout + the next
+        LayerNorm (+ the next layer's q|k|v projection)]: 5 launches + the memory's k|v projection instead of 13.  Forward only;
+        dropout sites are drawn in the order of `TransformerDecoderLayer.forward`, so a recomputation through the unfused
+        kernels sees the same masks."""
+        from phnet_amd import hip_ops as K
+        site = PF.DropoutStream.site
+        dev = x.device
+        x = x.contiguous()
+        first = self.layers[0]
+        e = x.shape[1]
+        _, _, qkv = K.rowchain_fwd(x, ln1=(first.norm1.weight, first.norm1.bias), wg=first.self_attn.in_proj_weight,
+                                   bg=first.self_attn.in_proj_bias, eps=first.norm1.eps, want_t=False)
+        h = None
+        for i, layer in enumerate(self.layers):
+            tr = layer.training
+            p_of = lambda d: d.p if tr else 0.0                                           # noqa: E731
+            sa, ca = layer.self_attn, layer.multihead_attn
+            a, _ = K.attention_fwd(qkv[:, :e], qkv[:, e:2 * e], qkv[:, 2 * e:], sa.num_heads, None,
+                                   rng=site(dev, sa.dropout if tr else 0.0), batch=batch)
+            t, _, q = K.rowchain_fwd(a, resid=x, wa=sa.out_proj.weight, ba=sa.out_proj.bias, ln1=(layer.norm2.weight, layer.norm2.bias),
+                                     wg=ca.in_proj_weight[:e], bg=ca.in_proj_bias[:e], eps=layer.norm2.eps, rng_a=site(dev, p_of(layer.dropout1)))
+            kv = K.linear_fwd(mem, ca.in_proj_weight[e:], ca.in_proj_bias[e:])
+            kvu8 = None if memory_key_valid is None else memory_key_valid.contiguous().view(torch.uint8)
+            a2, _ = K.attention_fwd(q, kv[:, :e], kv[:, e:], ca.num_heads, kvu8, rng=site(dev, ca.dropout if tr else 0.0), batch=batch)
+            nxt = self.layers[i + 1] if i + 1 < len(self.layers) else None
+            norm = nxt.norm1 if nxt is not None else self.norm
+            r_a, r_f, r_3 = site(dev, p_of(layer.dropout2)), site(dev, p_of(layer.dropout)), site(dev, p_of(layer.dropout3))
+            x, h, qkv = K.rowchain_fwd(a2, resid=t, wa=ca.out_proj.weight, ba=ca.out_proj.bias, ln1=(layer.norm3.weight, layer.norm3.bias),
+                                       ffn=(layer.linear1.weight, layer.linear1.bias, layer.linear2.weight, layer.linear2.bias),
+                                       ln2=(norm.weight, norm.bias) if norm is not None else (layer.norm3.weight, layer.norm3.bias),
+                                       wg=None if nxt is None else nxt.self_attn.in_proj_weight,
+                                       bg=None if nxt is None else nxt.self_attn.in_proj_bias, eps=layer.norm3.eps,
+                                       rng_a=r_a, rng_f=r_f, rng_3=r_3, want_t=True, want_h=nxt is None)
+        return h if self.norm is not None else x
+
+    def _can_fuse(self, x, mem) -> bool:
+        l0 = self.layers[0]
+        e, ff = x.shape[-1], l0.linear1.out_features
+        ps = {l.dropout.p for l in self.layers} | {l.dropout1.p for l in self.layers} | {l.dropout2.p for l in self.layers} | {l.dropout3.p for l in self.layers}
+        return (self.fuse_row_chains and not torch.is_grad_enabled() and x.is_cuda and (e, ff) in ((128, 256), (256, 512))
+                and l0.self_attn.embed_dim // l0.self_attn.num_heads in (16, 32) and len(ps) == 1 and self.norm is not None
+                and (e == 128 or not self.training))
+
     def forward(self, tgt: torch.Tensor, memory: torch.Tensor, memory_key_valid=None, batch: int = 1) -> torch.Tensor:
         """tgt [L,1,E] or [L,E]; memory [M,1,E] or [M,E]; memory_key_valid bool[M]; returns the same rank as tgt.
         batch = B: tgt [B*L,E], memory [B*M,E], mask [B*M] hold B clips as contiguous row blocks."""
         shape = tgt.shape
         x, mem = tgt.reshape(-1, shape[-1]), memory.reshape(-1, memory.shape[-1])
+        if self._can_fuse(x, mem):
+            return self._forward_row_chains(x, mem.contiguous(), memory_key_valid, batch).reshape(shape)
         h = None
         for i, layer in enumerate(self.layers):
             nxt = self.layers[i + 1].norm1 if i + 1 < len(self.layers) else self.norm

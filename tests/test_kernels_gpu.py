@@ -1097,3 +1097,72 @@ def test_dropout_masks_per_item_batched_equals_item_by_item():
         K.attention_bwd(qi, kvi[:, :H * D], kvi[:, H * D:], oi, do[qs].contiguous(), lsei, H, dqi, dkvi[:, :H * D], dkvi[:, H * D:], None,
                         rng=(state, 12, 0.3, i, 0))
         assert torch.equal(dqi, dq[qs]) and torch.equal(dkvi, dkv[ks])
+
+
+def _close_k(a, b, tol, what=""):
+    close(a, b, tol)
+
+
+@pytest.mark.parametrize("e,ff", [(128, 256), (256, 512)])
+def test_rowchain_vs_fp64_statement(e, ff):
+    """csrc/rowchain.hip: the three forms a decoder layer uses (LayerNorm + projection; out-projection + residual + LayerNorm +
+    projection; out-projection + residual + LayerNorm + feed-forward + residual + LayerNorm (+ projection)) against torch fp64,
+    on a row count that is not a multiple of the 16-row blocks."""
+    from phnet_amd import hip_ops as K
+    r_ = np.random.default_rng(e)
+    R = 37
+    def T(*shape, s=1.0):
+        return torch.from_numpy((r_.standard_normal(shape) * s).astype(np.float32)).cuda()
+    x, res = T(R, e), T(R, e)
+    wa, ba = T(e, e, s=e ** -0.5), T(e, s=0.1)
+    l1, l2 = (T(e).abs() + 0.5, T(e, s=0.1)), (T(e).abs() + 0.5, T(e, s=0.1))
+    w1, b1, w2, b2 = T(ff, e, s=e ** -0.5), T(ff, s=0.1), T(e, ff, s=ff ** -0.5), T(e, s=0.1)
+    wg, bg = T(3 * e, e, s=e ** -0.5), T(3 * e, s=0.1)
+    d = lambda t: t.double()                                                             # noqa: E731
+    # form 1
+    _, _, y = K.rowchain_fwd(x, ln1=l1, wg=wg, bg=bg, want_t=False)
+    ref = F.linear(F.layer_norm(d(x), [e], d(l1[0]), d(l1[1])), d(wg), d(bg))
+    _close_k(y, ref, 2e-5, "form 1")
+    # form 2
+    t, _, y = K.rowchain_fwd(x, resid=res, wa=wa, ba=ba, ln1=l1, wg=wg[:e], bg=bg[:e])
+    t_ref = d(res) + F.linear(d(x), d(wa), d(ba))
+    _close_k(t, t_ref, 2e-5, "form 2 t")
+    _close_k(y, F.linear(F.layer_norm(t_ref, [e], d(l1[0]), d(l1[1])), d(wg[:e]), d(bg[:e])), 2e-5, "form 2 y")
+    # form 3 (with and without the trailing projection)
+    for tail in (True, False):
+        t, h, y = K.rowchain_fwd(x, resid=res, wa=wa, ba=ba, ln1=l1, ffn=(w1, b1, w2, b2), ln2=l2, wg=wg if tail else None,
+                                 bg=bg if tail else None, want_h=True)
+        h1 = F.layer_norm(t_ref, [e], d(l1[0]), d(l1[1]))
+        t2 = t_ref + F.linear(F.gelu(F.linear(h1, d(w1), d(b1))), d(w2), d(b2))
+        h2 = F.layer_norm(t2, [e], d(l2[0]), d(l2[1]))
+        _close_k(t, t2, 2e-5, "form 3 t"); _close_k(h, h2, 2e-5, "form 3 h")
+        if tail:
+            _close_k(y, F.linear(h2, d(wg), d(bg)), 2e-5, "form 3 y")
+        else:
+            assert y is None
+
+
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_decoder_row_chain_forward_equals_unfused_forward(p):
+    """TransformerDecoder without autograd (fused row chains) against the same decoder under autograd (one launch per operation):
+    same values, and with dropout the same masks (both draw them from DropoutStream sites in the same order)."""
+    from phnet_amd import functional as PF
+    from phnet_amd.libs.models.utils.transformer import TransformerDecoder, TransformerDecoderLayer
+    torch.manual_seed(0)
+    layer = TransformerDecoderLayer(d_model=128, nhead=8, dim_feedforward=256, dropout=p, activation="gelu", normalize_before=True)
+    dec = TransformerDecoder(layer, 2, torch.nn.LayerNorm(128)).cuda().train()
+    r_ = np.random.default_rng(1)
+    for batch, lk in ((1, 40), (3, 25)):
+        tgt = torch.from_numpy(r_.standard_normal((batch * 240, 128)).astype(np.float32)).cuda()
+        mem = torch.from_numpy(r_.standard_normal((batch * lk, 128)).astype(np.float32)).cuda()
+        valid = torch.from_numpy(r_.uniform(size=batch * lk) > 0.3).cuda()
+        valid[::lk] = True
+        outs = []
+        for fused in (False, True):
+            with PF.DropoutStream.items(512, 2 if batch == 1 else 0, 0 if batch == 1 else 240):
+                if fused:
+                    with torch.no_grad():
+                        outs.append(dec(tgt, mem, valid, batch=batch))
+                else:
+                    outs.append(dec(tgt.clone().requires_grad_(), mem, valid, batch=batch).detach())
+        _close_k(outs[1], outs[0], 1e-4, f"decoder fused vs unfused, p = {p}, batch {batch}")

