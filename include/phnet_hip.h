@@ -310,6 +310,17 @@ int phnet_rowchain_fwd(const float* in, const float* resid, const float* Wa, con
                        int32_t R, int32_t E, int32_t FF, int32_t NG, float eps,
                        const uint64_t* rng_state, uint64_t call_a, uint64_t call_f, uint64_t call_3, float drop_p, void* stream);
 
+/* ---- tower weights of a lane-head branch (libs/models/Router4OL.py:68-99, 308-326: T towers of two Linear + ReLU layers and one
+ * Linear head each) assembled for the 3-GEMM chain, and their gradients scattered back: one launch each instead of the ~12
+ * torch.cat / block_diag launches per branch and clip and the ~40 of their autograd backward.  params / grads: HOST arrays of 6*T
+ * device pointers (per tower: layer-1 weight [C][C], bias [C], layer-2 weight, bias, head weight [o_t][C], head bias [o_t]).
+ * The assembled tensors live in ONE buffer w1 [TC][C] | b1 [TC] | w2 [TC][TC] | b2 [TC] | wh [HW][TC] | bh [HW]
+ * (phnet_tower_layout: its size, the six offsets, HW = sum o_t rounded up to a multiple of 4). ---- */
+uint64_t phnet_tower_layout(int32_t T, int32_t C, const int32_t* head_out, int64_t* offsets, int32_t* hw);
+int phnet_assemble_towers(const float* const* params, int32_t T, int32_t C, const int32_t* head_out, float* dst, void* stream);
+int phnet_scatter_tower_grads(const float* src, float* const* grads, int32_t T, int32_t C, const int32_t* head_out,
+                              int32_t accumulate, void* stream);
+
 /* ---- optimizer: one AdamW step (torch.optim.AdamW semantics, libs/utils/optimizer.py:33-35) over flat parameter / gradient /
  * moment arrays; elements [0, n_decay) get decoupled weight decay.  n % 4 == 0.  step: device int64, 1-based, already
  * incremented by the caller for this step.  lr_dev (optional): DEVICE pointer to the learning rate; when non-NULL it

@@ -474,3 +474,58 @@ def attention_cross(q: torch.Tensor, kv: torch.Tensor, heads: int, dropout_p: fl
                     key_valid: Optional[torch.Tensor] = None, batch: int = 1) -> torch.Tensor:
     """Cross-attention: q [B*Lq,E], kv [B*M,2E] packed (k|v), optional bool key mask [B*M] (per clip)."""
     return _Attention.apply(heads, dropout_p, key_valid, q, kv, batch)
+
+
+class _AssembleTowers(torch.autograd.Function):
+    """The T towers of a lane-head branch as the operands of ONE 3-GEMM chain (csrc/towers.hip): one launch writes the six assembled
+    tensors (views of one buffer); the weight-gradient kernels of their uses accumulate straight into a zero-initialised twin of
+    that buffer (arena.direct_grad finds it through `_phnet_sink`), and the backward scatters the twin into the parameters' own
+    gradient buffers with one launch - instead of ~12 torch.cat / block_diag launches forward and ~40 slice / add_ launches
+    backward per branch and clip."""
+
+    @staticmethod
+    def forward(ctx, c, head_out, pool, track, *params):
+        ctx.set_materialize_grads(False)
+        t = len(params) // 6
+        total, offs, hw = K.tower_layout(t, c, head_out)
+        dst = torch.empty(total, dtype=torch.float32, device=params[0].device)
+        K.assemble_towers(params, t, c, head_out, dst)
+        tc = t * c
+        shapes = [(tc, c), (tc,), (tc, tc), (tc,), (hw, tc), (hw,)]
+        ends = offs[1:] + [total]
+        outs = tuple(dst[o:e].view(sh) for o, e, sh in zip(offs, ends, shapes))
+        ctx.meta, ctx.params, ctx.buf = (t, c, list(head_out), offs, ends, shapes), params, None
+        if track:
+            from .arena import SinkPool                                       # noqa: F401
+            ctx.buf = pool.take(dst) if pool is not None else torch.zeros_like(dst)
+        return outs
+
+    @staticmethod
+    def backward(ctx, *gs):
+        from .arena import direct_grad
+        t, c, head_out, offs, ends, shapes = ctx.meta
+        src = ctx.buf
+        for g, o, e in zip(gs, offs, ends):                                    # gradients that came through autograd after all
+            if g is not None:
+                src = src.clone() if src is ctx.buf else src
+                src[o:e] += g.reshape(-1)
+        dests = [direct_grad(p) for p in ctx.params]
+        need = ctx.needs_input_grad[4:]
+        if all(d is not None for d, n in zip(dests, need) if n):
+            K.scatter_tower_grads(src, [d if n else None for d, n in zip(dests, need)], t, c, head_out, accumulate=True)
+            return (None, None, None, None) + (None,) * len(ctx.params)
+        outs = [torch.empty_like(p, memory_format=torch.contiguous_format) if n else None for p, n in zip(ctx.params, need)]
+        K.scatter_tower_grads(src, outs, t, c, head_out, accumulate=False)
+        return (None, None, None, None) + tuple(outs)
+
+
+def assemble_towers(c: int, head_out, pool, params):
+    """-> (w1, b1, w2, b2, wh, bh) for PF.linear chains; each carries its gradient sink when autograd is on."""
+    track = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+    outs = _AssembleTowers.apply(c, tuple(int(v) for v in head_out), pool, track, *params)
+    if track:
+        node = outs[0].grad_fn                                                # the Function's ctx: holds the sink buffer
+        _, _, _, offs, ends, shapes = node.meta
+        for o_, a, e, sh in zip(outs, offs, ends, shapes):
+            o_._phnet_sink = node.buf[a:e].view(sh)
+    return outs

@@ -855,6 +855,33 @@ def rowchain_fwd(x, resid=None, wa=None, ba=None, ln1=None, ffn=None, ln2=None, 
     return t, h, y
 
 
+def tower_layout(n_towers: int, c: int, head_out):
+    """-> (total floats, offsets[6] of w1 | b1 | w2 | b2 | wh | bh, HW) of the assembled tower weights (csrc/towers.hip)."""
+    import ctypes
+    ho = (ctypes.c_int32 * n_towers)(*[int(v) for v in head_out])
+    offs = (ctypes.c_int64 * 6)()
+    hw = ctypes.c_int32()
+    total = int(lib().phnet_tower_layout(n_towers, c, ho, offs, ctypes.byref(hw)))
+    if total == 0:
+        raise RuntimeError("phnet_tower_layout: bad arguments")
+    return total, list(offs), int(hw.value)
+
+
+def assemble_towers(params, n_towers: int, c: int, head_out, dst):
+    import ctypes
+    ho = (ctypes.c_int32 * n_towers)(*[int(v) for v in head_out])
+    check(lib().phnet_assemble_towers(_ptr_array([_req(p, name="tower parameter") for p in params]), n_towers, c, ho, _ptr(dst), _stream()),
+          "phnet_assemble_towers")
+    return dst
+
+
+def scatter_tower_grads(src, grads, n_towers: int, c: int, head_out, accumulate: bool):
+    import ctypes
+    ho = (ctypes.c_int32 * n_towers)(*[int(v) for v in head_out])
+    table = (ctypes.c_void_p * len(grads))(*[None if g is None else _req(g, name="tower gradient").data_ptr() for g in grads])
+    check(lib().phnet_scatter_tower_grads(_ptr(src), table, n_towers, c, ho, int(accumulate), _stream()), "phnet_scatter_tower_grads")
+
+
 DEFAULT_MMA = "bf16x3"
 
 

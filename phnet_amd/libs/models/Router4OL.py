@@ -152,6 +152,11 @@ class DetNetV2(nn.Module):
             g = lambda name: getattr(self, name + s)                                 # noqa: E731
             tw = [g("cls_modules"), g("reg_modules"), g("iou_modules")]
             hd = [g("cls_layers"), g("reg_layers"), g("iou_layers")]
+            params = [x for t, h in zip(tw, hd) for x in (t[0].weight, t[0].bias, t[2].weight, t[2].bias, h.weight, h.bias)]
+            if all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in params):
+                # one launch assembles the six operands, one launch scatters their gradients (csrc/towers.hip)
+                self._branch_cache[key] = PF.assemble_towers(tw[0][0].in_features, [h.out_features for h in hd], self._sink_pool, params)
+                return self._branch_cache[key]
             w1 = torch.cat([t[0].weight for t in tw], dim=0)
             b1 = torch.cat([t[0].bias for t in tw], dim=0)
             w2 = torch.block_diag(*[t[2].weight for t in tw])

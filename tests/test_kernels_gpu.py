@@ -1166,3 +1166,32 @@ def test_decoder_row_chain_forward_equals_unfused_forward(p):
                 else:
                     outs.append(dec(tgt.clone().requires_grad_(), mem, valid, batch=batch).detach())
         _close_k(outs[1], outs[0], 1e-4, f"decoder fused vs unfused, p = {p}, batch {batch}")
+
+
+def test_assembled_tower_weights_and_scattered_gradients():
+    """csrc/towers.hip: the six operands of the 3-GEMM tower chain against torch.cat / torch.block_diag, and the gradients of a
+    chain through them against autograd on the cat / block_diag spelling."""
+    from phnet_amd import functional as PF
+    r_ = np.random.default_rng(4)
+    C, outs = 64, (2, 4, 36)
+    def P(*shape):
+        return torch.nn.Parameter(torch.from_numpy(r_.standard_normal(shape).astype(np.float32) * 0.2).cuda())
+    params = [x for o in outs for x in (P(C, C), P(C), P(C, C), P(C), P(o, C), P(o))]
+    tow = [params[6 * t:6 * t + 6] for t in range(3)]
+    x = torch.from_numpy(r_.standard_normal((50, C)).astype(np.float32)).cuda()
+    w1, b1, w2, b2, wh, bh = PF.assemble_towers(C, outs, None, params)
+    rw1 = torch.cat([t[0] for t in tow]); rb1 = torch.cat([t[1] for t in tow])
+    rw2 = torch.block_diag(*[t[2] for t in tow]); rb2 = torch.cat([t[3] for t in tow])
+    rwh = torch.block_diag(*[t[4] for t in tow]); rbh = torch.cat([t[5] for t in tow])
+    assert torch.equal(w1, rw1) and torch.equal(b1, rb1) and torch.equal(w2, rw2) and torch.equal(b2, rb2)
+    assert wh.shape == (44, 3 * C) and torch.equal(wh[:42], rwh) and not wh[42:].any() and torch.equal(bh[:42], rbh) and not bh[42:].any()
+    g = torch.from_numpy(r_.standard_normal((50, 44)).astype(np.float32)).cuda()
+    y = PF.linear(PF.linear(PF.linear(x, w1, b1, relu=True), w2, b2, relu=True), wh, bh)
+    (y * g).sum().backward()
+    got = [p.grad.clone() for p in params]
+    for p in params:
+        p.grad = None
+    yr = F.linear(F.relu(F.linear(F.relu(F.linear(x.double(), rw1.double(), rb1.double())), rw2.double(), rb2.double())), rwh.double(), rbh.double())
+    (yr * g[:, :42].double()).sum().backward()
+    for a, p in zip(got, params):
+        close(a, p.grad, 2e-5)
