@@ -321,6 +321,13 @@ int phnet_assemble_towers(const float* const* params, int32_t T, int32_t C, cons
 int phnet_scatter_tower_grads(const float* src, float* const* grads, int32_t T, int32_t C, const int32_t* head_out,
                               int32_t accumulate, void* stream);
 
+/* ---- towers + heads + lane prior update of a branch in one launch, forward only (libs/models/Router4OL.py:308-345): per tower
+ * relu(x W1^T + b1) -> relu(. W2^T + b2) -> head; the heads concatenated are (cls 2 | reg 4 | offsets S); then the prior update of
+ * phnet_lane_update_fwd.  params: HOST array of 6*T device pointers, used where they are (no assembled copies).  C = 64 or 128. ---- */
+int phnet_tower_chain_fwd(const float* x, const float* const* params, int32_t T, int32_t C, const int32_t* head_out,
+                          const float* priors, const float* ys, float* preds, float* lines, int32_t R, int32_t S,
+                          float img_w, float img_h, void* stream);
+
 /* ---- optimizer: one AdamW step (torch.optim.AdamW semantics, libs/utils/optimizer.py:33-35) over flat parameter / gradient /
  * moment arrays; elements [0, n_decay) get decoupled weight decay.  n % 4 == 0.  step: device int64, 1-based, already
  * incremented by the caller for this step.  lr_dev (optional): DEVICE pointer to the learning rate; when non-NULL it

@@ -225,6 +225,74 @@ __global__ __launch_bounds__(NT) void rowchain_kernel(RowChain p)
         }, first_of<PRE, E / 16>(pg));
 }
 
+// ---- the towers of a branch + the lane prior update in one launch (forward only) ----------------------------------------------
+// Per tower t (cls / reg / offsets): h1 = relu(x @ W1_t^T + b1_t); h2 = relu(h1 @ W2_t^T + b2_t); head_t = h2 @ Wh_t^T + bh_t;
+// then the prior update of Router4OL.py:328-345 on (cls 2 | reg 4 | offsets S) - the arithmetic of lane_update_fwd_kernel
+// (elementwise.hip).  The per-tower parameters are used where they are: no concatenated / block-diagonal copies.
+struct TowerChain {
+    const float* p[18];                            // per tower: W1 [C][C], b1, W2 [C][C], b2, Wh [o][C], bh
+    int out[3];
+    const float *x, *priors, *ys;                  // [R][C], [R][6+S], [S]
+    float *preds, *lines;                          // [R][6+S]
+    int R, T, S;
+    float img_w, img_h;
+};
+
+template <int C>
+__global__ __launch_bounds__(NT) void tower_chain_kernel(TowerChain p)
+{
+    constexpr int CP = C + 4, HP = 3 * C + 4, DP = 96;
+    extern __shared__ __attribute__((aligned(16))) float rc_lds[];
+    float* xs = rc_lds;                       // [ROWS][CP]
+    float* h1 = xs + ROWS * CP;               // [ROWS][HP]
+    float* h2 = h1 + ROWS * HP;               // [ROWS][HP]
+    float* hd = h2 + ROWS * HP;               // [ROWS][DP]: cls 2 | reg 4 | offsets S
+    const long row0 = (long)blockIdx.x * ROWS;
+    const int R = p.R, S = p.S, W = 6 + S;
+    for (int i = threadIdx.x; i < ROWS * (C / 4); i += NT) {
+        const int r = i / (C / 4), c4 = (i - r * (C / 4)) * 4;
+        f4 v = {0.f, 0.f, 0.f, 0.f};
+        if (row0 + r < R) v = *reinterpret_cast<const f4*>(p.x + (size_t)(row0 + r) * C + c4);
+        *reinterpret_cast<f4*>(xs + r * CP + c4) = v;
+    }
+    __syncthreads();
+    for (int t = 0; t < p.T; ++t)
+        gemm16<C>(xs, CP, p.p[6 * t], p.p[6 * t + 1], C, [&](int r, int n, float v) { h1[r * HP + t * C + n] = fmaxf(v, 0.f); });
+    __syncthreads();
+    for (int t = 0; t < p.T; ++t)
+        gemm16<C>(h1 + t * C, HP, p.p[6 * t + 2], p.p[6 * t + 3], C, [&](int r, int n, float v) { h2[r * HP + t * C + n] = fmaxf(v, 0.f); });
+    __syncthreads();
+    int off = 0;
+    for (int t = 0; t < p.T; ++t) {
+        gemm16<C>(h2 + t * C, HP, p.p[6 * t + 4], p.p[6 * t + 5], p.out[t], [&](int r, int n, float v) { hd[r * DP + off + n] = v; });
+        off += p.out[t];
+    }
+    __syncthreads();
+    {
+#pragma clang fp contract(off)
+        const int lane = threadIdx.x & 63;
+        for (int r = threadIdx.x >> 6; r < ROWS; r += NT / 64) {
+            const long row = row0 + r;
+            if (row >= R) continue;
+            const float* pr = p.priors + (size_t)row * W;
+            const float* h = hd + r * DP;
+            float* po = p.preds + (size_t)row * W;
+            float* lo = p.lines + (size_t)row * W;
+            const float sy = pr[2] + tanhf(h[2]), sx = pr[3] + tanhf(h[3]), th = pr[4] + tanhf(h[4]);
+            const float tn = tanf(th * 3.14159265358979323846f + 1e-5f);
+            if (lane == 0) {
+                po[0] = lo[0] = h[0]; po[1] = lo[1] = h[1];
+                po[2] = lo[2] = sy; po[3] = lo[3] = sx; po[4] = lo[4] = th; po[5] = lo[5] = h[5];
+            }
+            for (int k = lane; k < S; k += 64) {
+                const float x = (sx * (p.img_w - 1.0f) + ((1.0f - p.ys[k] - sy) * p.img_h / tn)) / (p.img_w - 1.0f);
+                lo[6 + k] = x;
+                po[6 + k] = x + h[6 + k];
+            }
+        }
+    }
+}
+
 }  // namespace
 
 // One launch for the row-local chain described at the top of this file.  All matrices row-major with the reduction dimension
@@ -260,6 +328,34 @@ PHNET_API int phnet_rowchain_fwd(const float* in, const float* resid, const floa
             attr = true;
         }
         hipLaunchKernelGGL((rowchain_kernel<256, 512, false>), grid, dim3(NT), lds, (hipStream_t)stream, p);
+    } else return PHNET_ERR_ARG;
+    return phnet_launch_status();
+}
+
+// Towers + heads + lane prior update of a branch in one launch, forward only (libs/models/Router4OL.py:308-345).
+// params: HOST array of 6*T device pointers (per tower: layer-1 weight [C][C], bias, layer-2 weight, bias, head weight [o_t][C],
+// head bias); the head outputs concatenated must be (cls 2 | reg 4 | offsets S), i.e. sum o_t = 6 + S <= 96.  x [R][C], C = 64 or
+// 128; priors [R][6+S]; ys [S]; preds / lines [R][6+S].
+PHNET_API int phnet_tower_chain_fwd(const float* x, const float* const* params, int32_t T, int32_t C, const int32_t* head_out,
+                                    const float* priors, const float* ys, float* preds, float* lines, int32_t R, int32_t S,
+                                    float img_w, float img_h, void* stream)
+{
+    if (R < 0 || T < 1 || T > 3 || S < 1 || !head_out || !params) return PHNET_ERR_ARG;
+    if (R == 0) return PHNET_OK;
+    if (!x || !priors || !ys || !preds || !lines) return PHNET_ERR_ARG;
+    TowerChain p{};
+    int sum = 0;
+    for (int t = 0; t < T; ++t) { if (head_out[t] < 1) return PHNET_ERR_ARG; p.out[t] = head_out[t]; sum += head_out[t]; }
+    if (sum != 6 + S || sum > 96) return PHNET_ERR_ARG;
+    for (int i = 0; i < 6 * T; ++i) { if (!params[i]) return PHNET_ERR_ARG; p.p[i] = params[i]; }
+    p.x = x; p.priors = priors; p.ys = ys; p.preds = preds; p.lines = lines; p.R = R; p.T = T; p.S = S; p.img_w = img_w; p.img_h = img_h;
+    const dim3 grid((unsigned)ceil_div64(R, ROWS));
+    if (C == 64) {
+        const size_t lds = (size_t)ROWS * ((64 + 4) + 2 * (3 * 64 + 4) + 96) * sizeof(float);
+        hipLaunchKernelGGL((tower_chain_kernel<64>), grid, dim3(NT), lds, (hipStream_t)stream, p);
+    } else if (C == 128) {
+        const size_t lds = (size_t)ROWS * ((128 + 4) + 2 * (3 * 128 + 4) + 96) * sizeof(float);
+        hipLaunchKernelGGL((tower_chain_kernel<128>), grid, dim3(NT), lds, (hipStream_t)stream, p);
     } else return PHNET_ERR_ARG;
     return phnet_launch_status();
 }

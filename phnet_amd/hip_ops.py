@@ -882,6 +882,21 @@ def scatter_tower_grads(src, grads, n_towers: int, c: int, head_out, accumulate:
     check(lib().phnet_scatter_tower_grads(_ptr(src), table, n_towers, c, ho, int(accumulate), _stream()), "phnet_scatter_tower_grads")
 
 
+def tower_chain_fwd(x, params, head_out, priors, ys, img_w, img_h):
+    """x [R,C], params = 6*T tower tensors, priors [R,6+S] -> (preds, lines) [R,6+S]: towers + heads + lane prior update in one
+    launch (csrc/rowchain.hip), forward only."""
+    import ctypes
+    _req(x, name="x"); _req(priors, name="priors")
+    r, c = x.shape
+    t = len(params) // 6
+    ho = (ctypes.c_int32 * t)(*[int(v) for v in head_out])
+    preds, lines = torch.empty_like(priors), torch.empty_like(priors)
+    check(lib().phnet_tower_chain_fwd(_ptr(x), _ptr_array([_req(p, name="tower parameter") for p in params]), t, c, ho, _ptr(priors), _ptr(ys),
+                                      _ptr(preds), _ptr(lines), r, priors.shape[1] - 6, float(img_w), float(img_h), _stream()),
+          "phnet_tower_chain_fwd")
+    return preds, lines
+
+
 DEFAULT_MMA = "bf16x3"
 
 

@@ -170,7 +170,21 @@ class DetNetV2(nn.Module):
             self._branch_cache[key] = tuple(grad_sink(t, self._sink_pool) for t in (w1, b1, w2, b2, wh, bh))
         return self._branch_cache[key]
 
+    def _tower_params(self, sec: bool):
+        s = "_sec" if sec else ""
+        g = lambda name: getattr(self, name + s)                                     # noqa: E731
+        tw = [g("cls_modules"), g("reg_modules"), g("iou_modules")]
+        hd = [g("cls_layers"), g("reg_layers"), g("iou_layers")]
+        return [x for t, h in zip(tw, hd) for x in (t[0].weight, t[0].bias, t[2].weight, t[2].bias, h.weight, h.bias)], [h.out_features for h in hd]
+
     def _branch(self, feat, priors, sec: bool):
+        if not torch.is_grad_enabled() and feat.is_cuda and feat.shape[-1] in (64, 128):
+            # no autograd graph wanted (inference, the deferred branch-B passes): towers + heads + prior update in ONE launch
+            from phnet_amd import hip_ops as K
+            params, head_out = self._tower_params(sec)
+            preds, lines = K.tower_chain_fwd(feat.reshape(-1, feat.shape[-1]).contiguous(), params, head_out,
+                                             priors.reshape(-1, priors.shape[-1]).contiguous(), self.prior_ys, self.img_w, self.img_h)
+            return preds.view(priors.shape), lines.view(priors.shape)
         w1, b1, w2, b2, wh, bh = self._branch_weights(sec)
         h = PF.linear(feat, w1, b1, relu=True)
         h = PF.linear(h, w2, b2, relu=True)

@@ -1195,3 +1195,35 @@ def test_assembled_tower_weights_and_scattered_gradients():
     (yr * g[:, :42].double()).sum().backward()
     for a, p in zip(got, params):
         close(a, p.grad, 2e-5)
+
+
+@pytest.mark.parametrize("c", [64, 128])
+def test_tower_chain_forward_vs_fp64_statement(c):
+    """csrc/rowchain.hip tower_chain_kernel: the three towers, their heads and the lane prior update of a branch in one launch
+    against the same chain in torch fp64 (Router4OL.py:308-345)."""
+    from phnet_amd import hip_ops as K
+    r_ = np.random.default_rng(c)
+    S, R = 36, 53
+    outs = (2, 4, S)
+    def P(*shape, s=0.2):
+        return torch.from_numpy((r_.standard_normal(shape) * s).astype(np.float32)).cuda()
+    params = [x for o in outs for x in (P(c, c, s=c ** -0.5), P(c), P(c, c, s=c ** -0.5), P(c), P(o, c, s=0.3 * c ** -0.5), P(o, s=0.05))]
+    x = P(R, c, s=1.0)
+    pri = torch.zeros(R, 6 + S)
+    pri[:, 2] = torch.from_numpy(r_.uniform(0, 0.5, R)); pri[:, 3] = torch.from_numpy(r_.uniform(0.1, 0.9, R)); pri[:, 4] = torch.from_numpy(r_.uniform(0.15, 0.85, R))
+    pri = pri.float().cuda()
+    ys = torch.linspace(1, 0, S).cuda()
+    preds, lines = K.tower_chain_fwd(x, params, outs, pri, ys, 800, 320)
+    d = lambda t: t.double()                                                             # noqa: E731
+    heads = []
+    for t in range(3):
+        w1, b1, w2, b2, wh, bh = params[6 * t:6 * t + 6]
+        heads.append(F.linear(F.relu(F.linear(F.relu(F.linear(d(x), d(w1), d(b1))), d(w2), d(b2))), d(wh), d(bh)))
+    head = torch.cat(heads, dim=1)
+    ref_p, ref_l = _lane_update_reference(d(pri), head, d(ys), 800, 320, S)
+    # the tan() of the prior update amplifies the GEMMs' 1e-6 (f32 vs f64) near its poles: judge x columns against the row scale
+    for got, ref in ((preds, ref_p), (lines, ref_l)):
+        got, ref = got.cpu().double(), ref.cpu()
+        assert float((got[:, :6] - ref[:, :6]).abs().max()) <= 2e-5
+        scale = 1.0 + ref[:, 6:].abs().amax(dim=1, keepdim=True)
+        assert float(((got[:, 6:] - ref[:, 6:]).abs() / scale).max()) <= 2e-4
