@@ -197,6 +197,11 @@ int phnet_lane_assign(const float* pred, const float* tgt, int32_t N, int32_t L,
  * the reference's pair order, -1 padded; n_pairs (optional) i32. */
 int phnet_lane_assign_one2many(const float* pred, const float* tgt, int32_t N, int32_t L, int32_t S,
                                float img_w, float img_h, int64_t* rows, int64_t* cols, int32_t* n_pairs, void* stream);
+/* phnet_lane_assign + phnet_memory_tokens on its result in one launch (the pair the training schedule issues after every branch-B
+ * pass): feat [N][E] this frame's tokens, tokens [L+1][E] / valid u8 [L+1] the memory entry they leave (Router4OL.py:563-584). */
+int phnet_lane_assign_tokens(const float* pred, const float* tgt, int32_t N, int32_t L, int32_t S, float img_w, float img_h,
+                             int64_t* rows_by_col, int64_t* rows_sorted, const float* feat, int32_t E,
+                             float* tokens, uint8_t* valid, void* stream);
 
 /* ---- fused per-frame criterion: replaces Criterion4OL.loss4OneStep (libs/utils/loss4OLV3.py:34-82,100-123: assignment,
  * focal, smooth-L1, LaneIoU, gate-weighted combination) AND its autograd backward with two launches.

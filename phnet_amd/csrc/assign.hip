@@ -21,6 +21,41 @@ __global__ __launch_bounds__(4 * NT) void lane_assign_kernel(
     lane_assign_block<false, 4>(pred, tgt, N, L, S, img_w, img_h, rows_by_col, rows_sorted, n_valid_out, cost_out, cost);
 }
 
+// Assignment + the memory tokens it selects (Router4OL.py:563-584) in one launch: tokens [L+1][E] = the features of the matched
+// anchors in ascending anchor order (unused slots zero, valid = 0), then the mean of all other anchors; E <= 256.
+__global__ __launch_bounds__(4 * NT) void lane_assign_tokens_kernel(
+    const float* __restrict__ pred, const float* __restrict__ tgt, int N, int L, int S, float img_w, float img_h,
+    int64_t* __restrict__ rows_by_col, int64_t* __restrict__ rows_sorted, const float* __restrict__ feat, int E,
+    float* __restrict__ tokens, unsigned char* __restrict__ valid)
+{
+    extern __shared__ float cost[];                  // [N][MAXL], then [groups][E] column partial sums
+    float* part = cost + N * MAXL;
+    // column sums of the features do not depend on the assignment: their loads are in flight while it runs
+    const int e = threadIdx.x % E, grp = threadIdx.x / E, groups = (4 * NT) / E;
+    float s = 0.f;
+    if (grp < groups)
+        for (int n = grp; n < N; n += groups) s += feat[(size_t)n * E + e];
+    lane_assign_block<false, 4>(pred, tgt, N, L, S, img_w, img_h, rows_by_col, rows_sorted, nullptr, nullptr, cost);
+    if (grp < groups) part[grp * E + e] = s;
+    __syncthreads();                                 // also orders rows_sorted (written by thread 0) before the reads below
+    if (grp != 0) return;
+    float total = 0.f;
+    for (int g2 = 0; g2 < groups; ++g2) total += part[g2 * E + e];
+    float possum = 0.f;
+    int cnt = 0;
+    for (int l = 0; l < L; ++l) {
+        const long long r = rows_sorted[l];
+        const bool ok = r >= 0 && r < N;
+        const float v = ok ? feat[(size_t)r * E + e] : 0.f;
+        tokens[(size_t)l * E + e] = v;
+        possum += v;
+        cnt += ok;
+        if (e == 0) valid[l] = ok;
+    }
+    tokens[(size_t)L * E + e] = (total - possum) / (float)(N - cnt);
+    if (e == 0) valid[L] = 1;
+}
+
 __global__ __launch_bounds__(4 * NT) void lane_assign_many_kernel(
     const float* __restrict__ pred, const float* __restrict__ tgt, int N, int L, int S, float img_w, float img_h,
     int64_t* __restrict__ rows, int64_t* __restrict__ cols, int32_t* __restrict__ n_pairs)
@@ -57,5 +92,19 @@ PHNET_API int phnet_lane_assign_one2many(const float* pred, const float* tgt, in
     if (!pred || !tgt || !rows || !cols) return PHNET_ERR_ARG;
     hipLaunchKernelGGL(lane_assign_many_kernel, dim3(1), dim3(4 * NT), (size_t)2 * N * MAXL * sizeof(float), (hipStream_t)stream,
                        pred, tgt, N, L, S, img_w, img_h, rows, cols, n_pairs);
+    return phnet_launch_status();
+}
+
+// phnet_lane_assign followed by phnet_memory_tokens on its result, as one launch: feat [N][E] (E <= 256, 1024 % E == 0),
+// tokens [L+1][E], valid u8 [L+1].  L >= 1.
+PHNET_API int phnet_lane_assign_tokens(const float* pred, const float* tgt, int32_t N, int32_t L, int32_t S, float img_w, float img_h,
+                                       int64_t* rows_by_col, int64_t* rows_sorted, const float* feat, int32_t E,
+                                       float* tokens, uint8_t* valid, void* stream)
+{
+    if (N < 1 || N > NT || L < 1 || L > MAXL || S < 1 || S > 250 || E < 1 || E > 256 || (4 * NT) % E) return PHNET_ERR_ARG;
+    if (!pred || !tgt || !rows_by_col || !rows_sorted || !feat || !tokens || !valid) return PHNET_ERR_ARG;
+    const size_t lds = ((size_t)N * MAXL + (size_t)4 * NT) * sizeof(float);
+    hipLaunchKernelGGL(lane_assign_tokens_kernel, dim3(1), dim3(4 * NT), lds, (hipStream_t)stream,
+                       pred, tgt, N, L, S, img_w, img_h, rows_by_col, rows_sorted, feat, E, tokens, valid);
     return phnet_launch_status();
 }

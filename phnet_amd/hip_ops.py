@@ -520,6 +520,24 @@ def lane_assign(pred, tgt, img_w: int, img_h: int, want_cost: bool = False):
     return (rows, srt, nv, cost) if want_cost else (rows, srt, nv)
 
 
+def lane_assign_tokens(pred, tgt, img_w: int, img_h: int, feat, out):
+    """lane_assign(pred, tgt) + memory_tokens(feat, matched anchors, out=out) in one launch; out = (tokens [L+1,E] view, valid bool [L+1]).
+    Returns rows_sorted (i64[L], -1 padded)."""
+    _req(pred, name="pred"); _req(tgt, name="tgt"); _req(feat, name="feat")
+    n, w = pred.shape
+    L = tgt.shape[0]
+    e = feat.shape[-1]
+    tokens, valid = out
+    _req(tokens, name="tokens out")
+    if tokens.numel() != (L + 1) * e or valid.numel() != L + 1 or valid.dtype != torch.bool or not valid.is_contiguous() or feat.numel() != n * e:
+        raise ValueError("lane_assign_tokens: out buffers do not match (tokens [L+1,E] f32, valid [L+1] bool, contiguous)")
+    rows = torch.empty(L, dtype=torch.int64, device=pred.device)
+    srt = torch.empty(L, dtype=torch.int64, device=pred.device)
+    check(lib().phnet_lane_assign_tokens(_ptr(pred), _ptr(tgt), n, L, w - 6, float(img_w), float(img_h), _ptr(rows), _ptr(srt), _ptr(feat), e,
+                                         _ptr(tokens), _ptr(valid), _stream()), "phnet_lane_assign_tokens")
+    return srt
+
+
 def lane_assign_one2many(pred, tgt, img_w: int, img_h: int):
     """pred [N,6+S], tgt [L<=4,6+S] (all label rows, valid flag in column 1) -> (rows i64[16], cols i64[16], n i32[]): the
     (anchor, label row) pairs of dynamic_assign.assignOne2Many in the reference's order, -1 padded; no host sync."""

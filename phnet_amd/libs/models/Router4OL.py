@@ -619,9 +619,9 @@ class RouterOL(nn.Module):
                 mem = (ring[t:t + W].view(-1, 1, E), ring_valid[t:t + W].view(-1)) if t > 0 else None
                 with torch.set_grad_enabled(not defer), PF.DropoutStream.items(BRANCH_B_SITES, stage * (T - 1) + t - 1 if t else 0, 0):
                     pred_b, line_b = det.forward_second(mem, tok_t[t].transpose(0, 1), stage, pri_t[t])
-                with torch.no_grad():
-                    _, rows_sorted, _ = K.lane_assign(pred_b[0].detach().contiguous(), lanes[t].contiguous(), det.img_w, det.img_h)
-                    K.memory_tokens(tok_t[t].detach().contiguous(), rows_sorted.contiguous(), out=(ring[W + t], ring_valid[W + t]))
+                with torch.no_grad():                                            # assignment + the tokens it selects: one launch
+                    K.lane_assign_tokens(pred_b[0].detach().contiguous(), lanes[t].contiguous(), det.img_w, det.img_h,
+                                         tok_t[t].detach().contiguous(), (ring[W + t], ring_valid[W + t]))
                 preds_b.append(pred_b)
                 lines_b.append(line_b.detach())
             pa = front["pred_a"].split(1, dim=0)                                               # one cat in the backward

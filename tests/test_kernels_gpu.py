@@ -1227,3 +1227,23 @@ def test_tower_chain_forward_vs_fp64_statement(c):
         assert float((got[:, :6] - ref[:, :6]).abs().max()) <= 2e-5
         scale = 1.0 + ref[:, 6:].abs().amax(dim=1, keepdim=True)
         assert float(((got[:, 6:] - ref[:, 6:]).abs() / scale).max()) <= 2e-4
+
+
+def test_lane_assign_tokens_equals_the_two_launches():
+    from phnet_amd import hip_ops as K
+    from tests import synth
+    from oracle import phnet_cpu as O
+    g = O.Geometry()
+    r_ = np.random.default_rng(8)
+    base = O.priors_from_embeddings(O.initial_anchor_embeddings(g), g)[0]
+    for counts in ((3,), (0,), (4,), (1,)):
+        tgt = synth.make_targets(g, 1, counts=counts)[0].cuda()
+        pred = (base + torch.from_numpy(r_.normal(0, 0.02, base.shape).astype(np.float32))).cuda()
+        pred[:, :2] = torch.from_numpy(r_.normal(0, 1, (240, 2)).astype(np.float32)).cuda()
+        feat = torch.from_numpy(r_.standard_normal((240, 128)).astype(np.float32)).cuda()
+        _, srt, _ = K.lane_assign(pred, tgt, g.img_w, g.img_h)
+        tok_ref, val_ref = K.memory_tokens(feat, srt)
+        tok = torch.full((5, 128), 7.0, device="cuda"); val = torch.zeros(5, dtype=torch.bool, device="cuda")
+        srt2 = K.lane_assign_tokens(pred, tgt, g.img_w, g.img_h, feat, (tok, val))
+        assert torch.equal(srt2, srt) and torch.equal(val, val_ref)
+        close(tok, tok_ref.reshape(5, 128), 1e-6)
