@@ -227,6 +227,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("TORCH_NCCL_CUDA_EVENT_CACHE", "0")      # no event recycling between eager and captured collectives (graphed.py)
         torch.cuda.set_device(0 if args.share_gpu else local_rank)
         dist.init_process_group(backend=args.backend, init_method="env://")
     else:

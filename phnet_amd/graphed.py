@@ -16,6 +16,18 @@ from typing import Callable, Optional
 import torch
 
 
+def _drain_collective_watchdog(seconds: float = 0.5):
+    """Before a capture that contains collectives: let the process group's watchdog thread retire the EAGER collectives issued so
+    far.  It scans its work list every ~100 ms and queries their events; seen once in ~10 runs on this stack (torch 2.10 / RCCL
+    2.26): a scan that overlaps the capture dies with hipErrorCapturedEvent and takes the process down.  With the device idle and
+    the list empty when the capture starts there is nothing for it to query (captured collectives are never put on that list)."""
+    import time
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        torch.cuda.synchronize()
+        time.sleep(seconds)
+
+
 def data_parallel_step(model, arena, reducer, optimizer, frames, lanes, loss_divisor: float, stage_done=None):
     """One data-parallel training step, eagerly or under hipGraph capture:
     zero | trunk forward (staged, SyncBatchNorm exchanges inside) + lane head + loss | head backward | bucket 0 out |
@@ -63,6 +75,7 @@ class GraphedTrainStep:
                 self._step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        _drain_collective_watchdog()
         self.graph = torch.cuda.CUDAGraph()
         self.graph_opt = None
         if arena is None:

@@ -20,6 +20,7 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("TORCH_NCCL_CUDA_EVENT_CACHE", "0")      # no event recycling between eager and captured collectives (graphed.py)
         dist.init_process_group(backend=backend or ("nccl" if torch.cuda.is_available() else "gloo"), init_method="env://")
     return rank, world, local_rank
 

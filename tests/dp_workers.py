@@ -19,7 +19,7 @@ def free_port():
 
 def _worker(rank, world, port, backend, fn, ret, env):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
-                      HSA_ENABLE_IPC_MODE_LEGACY="0", **env)
+                      HSA_ENABLE_IPC_MODE_LEGACY="0", TORCH_NCCL_CUDA_EVENT_CACHE="0", **env)
     torch.set_num_threads(2)
     if backend != "gloo" or fn.__name__.startswith("gpu_"):
         torch.cuda.set_device(0)
