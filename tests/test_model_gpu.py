@@ -909,3 +909,43 @@ def test_criterion_variants_vs_reference_fixture(tag):
         if tag == "v2":
             k = int((matched[-1] >= 0).sum())
             assert res[2].shape == (1, 16, 42) and k == int((gold["v2_matched"][i, 2] >= 0).sum())
+
+
+def test_training_step_with_the_loss4ol_criterion_equals_oracle_on_the_same_head_outputs():
+    """trainOLV2.py's pairing: the Router4OL model with `libs.utils.loss4OL.Criterion4OL`.  One training step in the default
+    (stage-major, deferred branch-B backward) schedule: the clip loss equals the CPU oracle of that criterion evaluated on the head
+    outputs the model produced, and every parameter receives a finite gradient."""
+    from oracle import criterion_variants_cpu as OC
+    from phnet_amd.config import make_cfg
+    from phnet_amd.libs.models.Router4OL import RouterOL
+    from phnet_amd.libs.utils.loss4OL import Criterion4OL
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    g = O.Geometry(img_h=64, img_w=160, arch="resnet18")
+    cfg = make_cfg(img_h=g.img_h, img_w=g.img_w, arch=g.arch)
+    model = RouterOL(cfg, Criterion4OL(cfg))
+    model.load_state_dict(synth.make_state(g), strict=True)
+    for m in model.detNet.transformer_Dec.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+        if isinstance(m, torch.nn.MultiheadAttention):
+            m.dropout = 0.0
+    model = model.cuda().train()
+    T = 4
+    frames, lanes = synth.make_clip(g, T, seed=5).cuda(), synth.make_targets(g, T, counts=(3, 0, 4, 2)).cuda()
+    rec, undo = _record_heads(model)
+    loss = model({"frame": frames, "lanes": lanes})
+    loss.backward()
+    torch.cuda.synchronize()
+    undo()
+    ref = 0.0
+    for t in range(T):
+        fir = [rec["fir"][t][s].unsqueeze(0) for s in range(3)]
+        sec = [rec["sec"][t][s].unsqueeze(0) for s in range(3)]
+        gates = [rec["gate"][t][s].view(1, -1, 1) for s in range(3)]
+        matched, lt = OC.frame_loss_v1(fir, sec, gates, lanes[t:t + 1].cpu(), g)
+        ref += float(lt)
+        for s in range(3):
+            assert rec["matched"][t][s].tolist() == matched[s].tolist(), (t, s)
+    assert abs(float(loss) - ref) <= 2e-5 * abs(ref), (float(loss), ref)
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in model.parameters())
