@@ -126,7 +126,7 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(const float* __restrict__ 
     }
 }
 
-// role 0 (blockIdx.z == 0): dQ for a tile of 64 queries;  role 1: dK, dV for a tile of 64 keys.
+// role 0 (blockIdx.y < q_tiles): dQ for a tile of 16 queries;  role 1: dK, dV for a tile of 16 keys;  blockIdx.z = batch entry.
 __global__ __launch_bounds__(NT) void attn_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
                                                       const float* __restrict__ o, const float* __restrict__ dout,
                                                       const float* __restrict__ lse, const unsigned char* __restrict__ key_valid,

@@ -496,7 +496,6 @@ class _AssembleTowers(torch.autograd.Function):
         outs = tuple(dst[o:e].view(sh) for o, e, sh in zip(offs, ends, shapes))
         ctx.meta, ctx.params, ctx.buf = (t, c, list(head_out), offs, ends, shapes), params, None
         if track:
-            from .arena import SinkPool                                       # noqa: F401
             ctx.buf = pool.take(dst) if pool is not None else torch.zeros_like(dst)
         return outs
 

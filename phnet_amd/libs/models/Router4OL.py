@@ -128,7 +128,17 @@ class DetNetV2(nn.Module):
         return (sx * (self.img_w - 1) + ((1 - self.prior_ys - sy) * self.img_h / torch.tan(theta * math.pi + 1e-5))) / (self.img_w - 1)
 
     def _expand_anchors(self, emb: torch.Tensor):
-        sy, sx, theta = emb.split(1, dim=1)                              # one SplitBackward (a cat) instead of three slice backwards
+        if emb.is_cuda:
+            # the prior update with a zero head IS the anchor expansion (start / angle + tanh(0), length 0, xs of the straight
+            # line): one launch forward, one backward (phnet_lane_update_fwd / _bwd) instead of ~25 elementwise ATen launches
+            S = self.n_offsets
+            zero_head = getattr(self, "_zero_head", None)
+            if zero_head is None or zero_head.device != emb.device:
+                zero_head = self._zero_head = torch.zeros((1, self.num_priors, 6 + S), dtype=torch.float32, device=emb.device)
+            pri0 = torch.nn.functional.pad(emb, (2, 1 + S)).unsqueeze(0)                 # [1,N,6+S]: (0, 0, sy, sx, theta, 0, 0...)
+            pri = PF.lane_update(pri0, zero_head, self.prior_ys, self.img_w, self.img_h)[1][0]
+            return pri, pri[:, 6 + self.sample_x_indexs]
+        sy, sx, theta = emb.split(1, dim=1)                              # (module construction on the host: plain tensor ops)
         xs = self._line_xs(sy, sx, theta)
         z = emb.new_zeros(emb.shape[0], 1)
         pri = torch.cat([z, z, emb, z, xs], dim=1)
