@@ -74,6 +74,10 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL over xGMI; gloo only for "
                                                       "functional rehearsals of the N>1 path on a single GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--force-dp", action="store_true",
+                    help="rehearsal on ONE GPU: run the N > 1 code path (SyncBatchNorm containers, bucket reducer, RCCL collectives captured "
+                         "in the graph) in a one-rank process group with the collectives forced on - what the data-parallel machinery "
+                         "costs per step before any link is involved")
     return ap.parse_args()
 
 
@@ -225,10 +229,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    dp = world > 1 or args.force_dp                  # the data-parallel code path
+    if dp:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("TORCH_NCCL_CUDA_EVENT_CACHE", "0")      # no event recycling between eager and captured collectives (graphed.py)
-        torch.cuda.set_device(0 if args.share_gpu else local_rank)
+        if world == 1:
+            os.environ["PHNET_FORCE_COLLECTIVES"] = "1"
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+        torch.cuda.set_device(0 if (args.share_gpu or world == 1) else local_rank)
         dist.init_process_group(backend=args.backend, init_method="env://")
     else:
         torch.cuda.set_device(0)
@@ -248,7 +257,7 @@ def main():
     net = model
     from phnet_amd import parallel
     from phnet_amd.arena import GradArena
-    if world > 1:
+    if dp:
         # the reference's data-parallel model (trainOL.py:141-146): SyncBatchNorm containers + same initial weights on every
         # rank (DDP's constructor broadcast); gradient averaging is the overlapped bucket reducer below instead of DDP's hooks
         model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
@@ -275,11 +284,11 @@ def main():
     # N > 1: 4 gradient buckets in backward order (lane head | neck + layer4 | layer3 | rest), each all-reduced (SUM of
     # gradients pre-divided by the world size) as soon as the backward has finished it - the head bucket, 77 % of the
     # bytes, hides behind the whole trunk backward
-    reducer = parallel.BucketReducer(arena.flat, arena.bucket_bounds) if world > 1 else None
+    reducer = parallel.BucketReducer(arena.flat, arena.bucket_bounds) if dp else None
     from phnet_amd.graphed import GraphedTrainStep, data_parallel_step
 
     def step(i):
-        if world > 1:
+        if dp:
             return data_parallel_step(model, arena, reducer, opt, clips[i % len(clips)], lanes, T * CB * world)
         arena.zero()
         loss = net({"frame": clips[i % len(clips)], "lanes": lanes}) / (T * CB)
@@ -288,12 +297,12 @@ def main():
         return loss
 
     graphed = None
-    if use_graph and world > 1 and args.backend != "nccl":
+    if use_graph and dp and args.backend != "nccl":
         use_graph = False                            # only RCCL collectives can be captured; a gloo rehearsal runs eagerly
     if use_graph:
         try:
             graphed = GraphedTrainStep(model, opt, clips[0], lanes, loss_divisor=T * CB * world, warmup=2, arena=arena, reducer=reducer)
-            print("[bench] training step captured in a hipGraph" + ("" if world == 1 else " (RCCL collectives inside)"), file=sys.stderr, flush=True)
+            print("[bench] training step captured in a hipGraph" + (" (RCCL collectives inside)" if dp else ""), file=sys.stderr, flush=True)
         except Exception as e:                                       # noqa: BLE001
             print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr, flush=True)
             graphed = None
@@ -407,10 +416,10 @@ def main():
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": DTYPE[args.mma], "data": "synthetic",
                "config": {"workload": f"{T}-frame clip 3x{args.height}x{args.width}, {args.arch} + router + lane head, fwd+bwd+AdamW, "
-                                      f"{CB} clip{'s' if CB > 1 else ''}/GPU/step, random-init weights", "parallelism": f"dp{world}",
+                                      f"{CB} clip{'s' if CB > 1 else ''}/GPU/step, random-init weights", "parallelism": f"dp{world}" + (" (data-parallel code path forced on one rank)" if dp and world == 1 else ""),
                           "timed_region": "grad-arena memset + forward + loss + backward (+ when N>1: SyncBatchNorm statistic exchanges and "
                                           "4 RCCL gradient-bucket all-reduces overlapped with the trunk backward) + AdamW step",
-                          "launch": ("hipGraph replay of the whole step" if world == 1 else
+                          "launch": ("hipGraph replay of the whole step" if not dp else
                                      "hipGraph replay of the whole step, RCCL collectives captured inside the graph")
                                     if graphed is not None else "eager"},
                "loss": round(float(loss.item()) * world, 4), "roofline": roof, "cpu_baseline": cpu}
@@ -425,7 +434,7 @@ def main():
             if inf is not None:
                 out["inference"] = inf
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dp:
         dist.destroy_process_group()
 
 

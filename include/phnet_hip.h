@@ -142,6 +142,8 @@ int phnet_bn_bwd_apply(const float* dy, const float* x, const float* y, const fl
  * fwd: phnet_bn_local_sums -> all-reduce(SUM) sums[2C+1] (fp64: sum x, sum x^2, count) -> phnet_bn_finalize_sums -> phnet_bn_apply
  * bwd: phnet_bn_bwd_reduce -> all-reduce(SUM) sums[2][C] -> phnet_bn_bwd_apply_sums (count = &sums_fwd[2C]) */
 int phnet_bn_local_sums(const float* x, int64_t M, int32_t C, float* partial, double* sums, void* stream);
+/* the same sums from the per-block partials of the convolution's epilogue (phnet_conv2d_fwd_fused stats): no pass over x */
+int phnet_bn_partials_to_sums(const float* partial, int64_t nblk, int64_t M, int32_t C, double* sums, void* stream);
 int phnet_bn_finalize_sums(const double* sums, int32_t C, float eps, float momentum, const float* gamma, const float* beta,
                            float* running_mean, float* running_var, float* save_mean, float* save_invstd,
                            float* scale, float* shift, void* stream);

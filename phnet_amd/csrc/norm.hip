@@ -211,24 +211,17 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(
 
 // ---- cross-rank (SyncBatchNorm) pieces: everything stays on the device, the caller only all-reduces two small buffers ----
 // sums [2C+1] fp64 = (sum x [C], sum x^2 [C], element count) of THIS rank: additive across ranks
-__global__ __launch_bounds__(NT) void bn_local_sums_kernel(const float* __restrict__ partial, int nblk, long M, int C,
-                                                           double* __restrict__ sums)
+__global__ __launch_bounds__(FIN_NT) void bn_local_sums_kernel(const float* __restrict__ partial, int nblk, long M, int C,
+                                                               double* __restrict__ sums)
 {
-    const int c = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (c >= C) return;
-    double s = 0.0, ss = 0.0;
-    for (int b = lane; b < nblk; b += 64) {
-        s += (double)partial[(size_t)b * 2 * C + c];
-        ss += (double)partial[(size_t)b * 2 * C + C + c];
-    }
-    s = wave_sum_f64(s);
-    ss = wave_sum_f64(ss);
-    if (lane == 0) {
-        sums[c] = s;
-        sums[C + c] = ss;
-        if (c == 0) sums[2 * C] = (double)M;
-    }
+    __shared__ double red[2 * FIN_NT];
+    const int c = blockIdx.x * FIN_CH + threadIdx.x % FIN_CH;
+    double s, ss;
+    finalize_column_sums(partial, nblk, C, red, s, ss);
+    if (threadIdx.x >= FIN_CH || c >= C) return;
+    sums[c] = s;
+    sums[C + c] = ss;
+    if (c == 0) sums[2 * C] = (double)M;
 }
 
 // (all-reduced) sums -> statistics of the union batch, running statistics (unbiased variance with the GLOBAL count, like
@@ -536,7 +529,17 @@ PHNET_API int phnet_bn_local_sums(const float* x, int64_t M, int32_t C, float* p
     hipLaunchKernelGGL(channel_partials_kernel<0>, dim3(nblk), dim3(NT), 2 * NT * sizeof(f32x4), st,
                        x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
                        partial, (long)M, C, rpb, 0);
-    hipLaunchKernelGGL(bn_local_sums_kernel, dim3((C + 3) / 4), dim3(NT), 0, st, (const float*)partial, nblk, (long)M, C, sums);
+    hipLaunchKernelGGL(bn_local_sums_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_NT), 0, st, (const float*)partial, nblk, (long)M, C, sums);
+    return phnet_launch_status();
+}
+
+// step 1 from per-block (sum, sum of squares) partials that the convolution's epilogue (or its split-K reduce) wrote
+// (phnet_conv2d_fwd_fused(..., stats = partial)): no pass over x.
+PHNET_API int phnet_bn_partials_to_sums(const float* partial, int64_t nblk, int64_t M, int32_t C, double* sums, void* stream)
+{
+    if (M < 1 || nblk < 1 || nblk > 0x7fffffff || !channels_ok(C) || !partial || !sums) return PHNET_ERR_ARG;
+    hipLaunchKernelGGL(bn_local_sums_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_NT), 0, (hipStream_t)stream, partial, (int)nblk, (long)M, C,
+                       sums);
     return phnet_launch_status();
 }
 

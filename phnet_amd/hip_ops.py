@@ -319,7 +319,7 @@ def bn_bwd(dy, x, y, save_mean, save_invstd, gamma, relu: bool, dres: Optional[t
 
 
 def bn_fwd_sync(x, gamma, beta, running_mean, running_var, eps: float, momentum: float, residual=None, relu: bool = True,
-                group=None):
+                group=None, partials=None):
     """Training-mode BatchNorm whose statistics span the ranks of `group` (nn.SyncBatchNorm, trainOL.py:141), without any
     host round trip: local fp64 (sum x, sum x^2, count) -> ONE all-reduce of 2C+1 doubles -> statistics of the union batch,
     running statistics, scale / shift on the device.  Returns (y, mean, invstd, count) with `count` a device view (fp64[1])
@@ -331,8 +331,11 @@ def bn_fwd_sync(x, gamma, beta, running_mean, running_var, eps: float, momentum:
     dev = x.device
     stats = torch.empty(4, c, dtype=torch.float32, device=dev)          # mean, invstd, scale, shift
     sums = torch.empty(2 * c + 1, dtype=torch.float64, device=dev)
-    part = _partials(m, c, dev)
-    check(lib().phnet_bn_local_sums(_ptr(x), m, c, _ptr(part), _ptr(sums), _stream()), "phnet_bn_local_sums")
+    if partials is not None and partials[0] is not None:                # (sum, sum of squares) partials from the conv epilogue
+        check(lib().phnet_bn_partials_to_sums(_ptr(partials[0]), int(partials[1]), m, c, _ptr(sums), _stream()), "phnet_bn_partials_to_sums")
+    else:
+        part = _partials(m, c, dev)
+        check(lib().phnet_bn_local_sums(_ptr(x), m, c, _ptr(part), _ptr(sums), _stream()), "phnet_bn_local_sums")
     parallel.allreduce_sum_(sums, group)
     check(lib().phnet_bn_finalize_sums(_ptr(sums), c, eps, momentum, _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
                                        _ptr(stats[0]), _ptr(stats[1]), _ptr(stats[2]), _ptr(stats[3]), _stream()), "phnet_bn_finalize_sums")

@@ -68,10 +68,14 @@ def _conv_bn(tape: list, x, conv: nn.Conv2d, bn, training: bool, relu: bool, res
         rec.c = rec.y = K.conv2d_fwd(x, wf, bf, rec.stride, rec.pad, relu=relu, addend=residual)
         rec.sm = rec.si = None
     elif training and _sync_bn(bn):
-        rec.c = K.conv2d_fwd(x, rec.w, None, rec.stride, rec.pad)
+        co = rec.w.shape[0]
+        if co <= 1024 and (co & (co - 1)) == 0:                   # local statistics from the convolution's own epilogue, as below
+            rec.c, partials = K.conv2d_fwd(x, rec.w, None, rec.stride, rec.pad, stats=True)
+        else:
+            rec.c, partials = K.conv2d_fwd(x, rec.w, None, rec.stride, rec.pad), None
         rec.y, rec.sm, rec.si, rec.sync_count = K.bn_fwd_sync(rec.c, bn.weight.detach(), bn.bias.detach(), bn.running_mean,
                                                               bn.running_var, bn.eps, mom, residual, relu,
-                                                              getattr(bn, "process_group", None))
+                                                              getattr(bn, "process_group", None), partials=partials)
     else:
         # training: the batch statistics come out of the convolution's own epilogue (per-slab partial sums), no second pass
         co = rec.w.shape[0]
