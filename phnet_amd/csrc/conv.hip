@@ -204,7 +204,11 @@ __device__ __forceinline__ void igemm_tile(
     auto load_global = [&](int kt, f32x4 (&a_reg)[A_LOADS], f32x4 (&b_reg)[B_LOADS], f32x4 (&a_relu)[AMASK ? A_LOADS : 1], unsigned& mask) {
         mask = 0;
         if constexpr (BUF) {
+#ifdef PHNET_FAKE_NOLOAD             /* timing experiment only: every tile after the first ring is an out-of-range (zero-fill, no traffic) load */
+            const bool tile_ok = kt < k_begin + PF * BKT;
+#else
             const bool tile_ok = kt < k_end;                             // uniform: K and the split bounds are multiples of BKT
+#endif
             const int s_tap = ((ur * g.Wi + uq) * g.Ci + uc0) * 4;
 #pragma unroll
             for (int i = 0; i < A_LOADS; ++i) {
@@ -293,14 +297,23 @@ __device__ __forceinline__ void igemm_tile(
                 v.x = a_relu[i].x > 0.f ? v.x : 0.f; v.y = a_relu[i].y > 0.f ? v.y : 0.f;
                 v.z = a_relu[i].z > 0.f ? v.z : 0.f; v.w = a_relu[i].w > 0.f ? v.w : 0.f;
             }
+#ifdef PHNET_FAKE_NOAW
+            if (S3) { if (v.x == 12345.678f) store_split3<AP3::PLANE>(a3, (a_row + ROWS_PER_PASS * i) * AP3::PITCH + a_chunk * 8, v); } else
+#else
             if (S3) store_split3<AP3::PLANE>(a3, (a_row + ROWS_PER_PASS * i) * AP3::PITCH + a_chunk * 8, v);
-            else *reinterpret_cast<f32x4*>(a + (a_row + ROWS_PER_PASS * i) * A_PITCH + a_chunk * 4) = v;
+            else
+#endif
+            *reinterpret_cast<f32x4*>(a + (a_row + ROWS_PER_PASS * i) * A_PITCH + a_chunk * 4) = v;
         }
         if (!B_DGRAD) {
 #pragma unroll
             for (int i = 0; i < B_LOADS; ++i) {
                 const f32x4 v = BUF ? b_reg[i] : ((mask >> (16 + i)) & 1u ? b_reg[i] : zero);
+#ifdef PHNET_FAKE_NOBW
+                if (S3) { if (v.x == 12345.678f) store_split3<BP3C::PLANE>(b3, (a_row + ROWS_PER_PASS * i) * BP3C::PITCH + a_chunk * 8, v); }
+#else
                 if (S3) store_split3<BP3C::PLANE>(b3, (a_row + ROWS_PER_PASS * i) * BP3C::PITCH + a_chunk * 8, v);
+#endif
                 else *reinterpret_cast<f32x4*>(b + (a_row + ROWS_PER_PASS * i) * B_PITCH + a_chunk * 4) = v;
             }
         } else {
@@ -338,7 +351,13 @@ __device__ __forceinline__ void igemm_tile(
 #pragma unroll
             for (int ks = 0; ks < BKT / BK; ++ks) {
                 Frag3 a[FM], b[FN];
+#ifdef PHNET_FAKE_NOREAD
+                if (kt == k_begin)
+#endif
                 read_kcontig3<FM, AP3::PITCH, AP3::PLANE>(A3 + buf * AP3::BYTES + wm * AP3::PITCH, lane, ks, a);
+#ifdef PHNET_FAKE_NOREAD
+                if (kt == k_begin)
+#endif
                 if (!B_DGRAD) read_kcontig3<FN, BP3C::PITCH, BP3C::PLANE>(B3 + buf * B3_BYTES + wn * BP3C::PITCH, lane, ks, b);
                 else read_kstrided3<FN, BP3S::PITCH, BP3S::PLANE>(B3 + buf * B3_BYTES + wn * 2, lane, ks, b);
                 mma3_step<FM, FN>(a, b, acc);
@@ -409,7 +428,9 @@ __device__ __forceinline__ void igemm_tile(
                     __builtin_amdgcn_sched_group_barrier(0x002, (14 + FM * FN - 1) / (FM * FN), 0);
                 }
             }
+#ifndef PHNET_FAKE_NOBAR
             __syncthreads();
+#endif
             PHNET_STAMP(st_bar, tprev);
             buf ^= 1;
         };
@@ -792,6 +813,188 @@ __global__ __launch_bounds__(THREADS) void conv_wgrad_kernel(
     }
 }
 
+// ---- weight gradient of a 3x3 / stride 1 / pad 1 convolution: the three taps of a filter row from ONE staged pixel block ----
+// The generic kernel above treats the 9 taps as 9 column tiles: every (co tile, tap, ci tile) workgroup loads, splits and
+// stages its own dY block and its own (shifted) X block.  The taps (dy, -1), (dy, 0), (dy, +1) read the SAME 16 dY pixels and
+// X rows that differ by one pixel, so here one workgroup of 12 waves stages dY[16 px][64 co] and X[18 px][64 ci] once per K
+// step and three groups of 4 waves multiply them - group dx reads the X planes one row further down and, where a pixel of
+// the block sits on the image border its tap would cross (x = 0 for dx = -1, x = W-1 for dx = +1: at most one pixel per 16,
+// W >= 16), clears that pixel's element of its dY fragment.  Loads, split arithmetic and LDS fills per MFMA fall 2.8x; the
+// output tile (3 x 64x64) and the partial-sum traffic per MFMA stay what they were.  X rows whose image row y + dy falls
+// outside the frame are staged as zeros (the pixel block may span image rows and frames: rows are tested one by one).
+// bf16x3 arithmetic, buffer loads; Ci, Co multiples of 64.
+constexpr int W3_THREADS = 768;
+int g_wgrad3 = 1, g_wgrad3_target = 256;                     // tuning aids (phnet_tune_wgrad: bit 3 of arg 0 switches it off; a negative
+                                                             // second argument sets its workgroup target)
+template <int PF>
+__global__ __launch_bounds__(W3_THREADS) void conv_wgrad3x3_kernel(
+    const float* __restrict__ dY, const float* __restrict__ X, float* __restrict__ out, float* __restrict__ dbias,
+    WgradShape g, int want_bias, int accumulate)
+{
+    constexpr int BKW = BK;                                  // 16 pixels per K step
+    constexpr int ROWS = BKW + 2;                            // X rows of a step: pixels pt-1 .. pt+16 of the shifted image row
+    constexpr int PITCH = KStridedPlanes<64, BKW>::PITCH;    // 192 bytes: 64 bf16 + pad (igemm.h)
+    constexpr int PLANE = ROWS * PITCH, IMG = 3 * PLANE;     // both operands use the 18-row image (dY leaves two rows unused)
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[4 * IMG + 2 * PLANE + 512];    // + a dump area (one slot per plane) for the idle staging lanes
+    unsigned char* A3 = lds_raw;                             // [buf][plane][row][col]
+    unsigned char* B3 = lds_raw + 2 * IMG;
+
+    const int NC = 9 * g.Ci, W = g.Wi, H = g.Hi;
+    const int P = g.N * H * W;
+    const int ctiles = g.Ci >> 6;
+    const unsigned tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int dyi = (int)(tile % 3), ct = (int)((tile / 3) % ctiles), mt = (int)(tile / (3 * ctiles));
+    const int m0 = mt * 64, c0 = ct * 64, dy = dyi - 1;
+    const int p_begin = blockIdx.z * g.pix_per_split, p_end = min(P, p_begin + g.pix_per_split);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tg = wave >> 2, dx = tg - 1;                   // tap group of this wave
+    const int wm = ((wave >> 1) & 1) * 32, wn = (wave & 1) * 32;
+
+    // ---- staging roles (wave-uniform): waves 0-3 dY, waves 4-7 X rows 0-15, wave 8 (first half) X rows 16-17 ----
+    const bool role_a = wave < 4;
+    const int st = tid - (role_a ? 0 : 256);
+    const int kk = st >> 4, col = (st & 15) * 4;             // row of the image, first of 4 columns
+    const bool active = wave < 8 || (wave == 8 && lane < 32);
+    const float* src = role_a ? dY : X;
+    const int cs = role_a ? g.Co : g.Ci;                     // channels of the source tensor
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (int)min((long)P * cs * 4, (long)0x7fffffff), 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    // dY: element (pt + kk, m0 + col); X: aligned pixel t = pt - 1 + kk, source pixel t + dy * W, channel c0 + col
+    const int off_c = role_a ? (kk * cs + m0 + col) * 4 : ((kk - 1 + dy * W) * cs + c0 + col) * 4;
+    int t_cur = p_begin + kk - (role_a ? 0 : 1);             // dY: the pixel; X: the aligned pixel
+    int t_x, t_y;
+    {
+        const int tt = t_cur + W * H;                        // >= 0; same (x, y) as t_cur
+        const int rowi = tt / W;
+        t_x = tt - rowi * W;
+        t_y = rowi % H;
+    }
+    f32x4 set[PF];
+    f32x4 bsum = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool bias_block = want_bias && ct == 0 && dyi == 0;
+    // loads the K step that starts at pixel pt; MUST be called with pt = p_begin, p_begin + 16, ... in order (branch-free)
+    auto load_global = [&](int pt, f32x4& reg) {
+        const bool ok_a = t_cur < p_end;
+        const bool ok_b = (unsigned)t_cur < (unsigned)P && (unsigned)(t_y + dy) < (unsigned)H;
+        const bool ok = active && (role_a ? ok_a : ok_b);
+        reg = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok ? off_c + pt * cs * 4 : (int)OOB, 0, 0));
+        t_cur += BKW;
+        t_x += BKW;
+        const int wx = t_x >= W;
+        t_x -= wx ? W : 0;
+        t_y += wx;
+        t_y = t_y == H ? 0 : t_y;
+    };
+    // branch-free (the loop body stays one basic block, so that the scheduler can interleave the split with the MFMAs): lanes
+    // without a staging job write their (zero) chunk into a dump slot behind the images
+    const float bflag = (role_a && bias_block) ? 1.f : 0.f;
+    const int st_off = active ? (role_a ? 0 : 2 * IMG) + kk * PITCH + col * 2 : 4 * IMG + lane * 8;
+    auto store_lds = [&](int buf, const f32x4& v) {
+        bsum += v * bflag;
+        store_split3<PLANE>(lds_raw, st_off + (active ? buf * IMG : 0), v);
+    };
+
+    const bool from_old = g.splits == 1 && accumulate;
+    const int n_base = (dyi * 3 + tg) * g.Ci + c0 + wn;      // first column of this wave's block in [Co][9 Ci]
+    f32x16 acc[1][1];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int n = n_base + frag_col(lane), m = m0 + wm + frag_row(lane, e);
+        const float v = out[from_old ? (size_t)m * NC + n : 0];
+        acc[0][0][e] = from_old ? v : 0.f;
+    }
+
+    if (p_begin < p_end) {
+        // Software pipeline over the K steps (all 12 waves of the CU's one workgroup run in lock-step, so nothing else hides an
+        // LDS round trip): in iteration t the fragments of step t+1 are fetched from LDS into a second register set, step t is
+        // multiplied from the set fetched an iteration ago, step t+2 moves from its ring slot into the LDS image step t has
+        // just left, and the ring slot takes step t+2+PF.  One barrier per step.
+        const int nsteps = (p_end - p_begin + BKW - 1) / BKW;
+        int mx = p_begin % W;                                // x of the first pixel of the step being multiplied
+        static_assert(PF % 2 == 0, "the step parity is read off the ring slot");
+#pragma unroll
+        for (int d = 0; d < PF; ++d) load_global(p_begin + d * BKW, set[d]);
+        store_lds(0, set[0]);
+        load_global(p_begin + PF * BKW, set[0]);
+        store_lds(1, set[1 % PF]);
+        load_global(p_begin + (PF + 1) * BKW, set[1 % PF]);
+        __syncthreads();
+        Frag3 fa[2], fb[2];
+        const unsigned char* a_src = A3 + wm * 2;
+        const unsigned char* b_src = B3 + (dx + 1) * PITCH + wn * 2;
+        {
+            Frag3 (&a0)[1] = *reinterpret_cast<Frag3 (*)[1]>(&fa[0]);
+            Frag3 (&b0)[1] = *reinterpret_cast<Frag3 (*)[1]>(&fb[0]);
+            read_kstrided3<1, PITCH, PLANE>(a_src, lane, 0, a0);
+            read_kstrided3<1, PITCH, PLANE>(b_src, lane, 0, b0);
+        }
+        const int h8 = (lane >> 5) * 8;
+        // clears, in a dY fragment, the pixel of the block starting at image column x0 whose tap dx leaves the image row
+        // (this lane holds k = h8 .. h8 + 7; no such pixel: element index -1)
+        auto mask_edge = [&](Frag3& a, int x0) {
+            const int ke = dx < 0 ? (x0 == 0 ? 0 : W - x0) : W - 1 - x0;
+            const int j = (dx != 0 && ke < BKW) ? ke - h8 : -1;
+            const int ji = j >> 1;                            // register of the element (negative: none)
+            const unsigned wmask = (j & 1) ? 0x0000ffffu : 0xffff0000u;
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            u32x4 m;
+            m.x = ji == 0 ? wmask : 0xffffffffu; m.y = ji == 1 ? wmask : 0xffffffffu;
+            m.z = ji == 2 ? wmask : 0xffffffffu; m.w = ji == 3 ? wmask : 0xffffffffu;
+            a.hi = __builtin_bit_cast(bf16x8, __builtin_bit_cast(u32x4, a.hi) & m);
+            a.mid = __builtin_bit_cast(bf16x8, __builtin_bit_cast(u32x4, a.mid) & m);
+            a.lo = __builtin_bit_cast(bf16x8, __builtin_bit_cast(u32x4, a.lo) & m);
+        };
+        mask_edge(fa[0], mx);
+        auto iteration = [&](auto U, int tt) {
+            constexpr int u = decltype(U)::value;             // tt % PF
+            constexpr int cur = u & 1, nxt = cur ^ 1, slot = (u + 2) % PF;
+            {
+                Frag3 (&an)[1] = *reinterpret_cast<Frag3 (*)[1]>(&fa[nxt]);
+                Frag3 (&bn)[1] = *reinterpret_cast<Frag3 (*)[1]>(&fb[nxt]);
+                read_kstrided3<1, PITCH, PLANE>(a_src + nxt * IMG, lane, 0, an);
+                read_kstrided3<1, PITCH, PLANE>(b_src + nxt * IMG, lane, 0, bn);
+            }
+            Frag3 (&a)[1] = *reinterpret_cast<Frag3 (*)[1]>(&fa[cur]);
+            Frag3 (&b)[1] = *reinterpret_cast<Frag3 (*)[1]>(&fb[cur]);
+            mma3_step<1, 1>(a, b, acc);
+            store_lds(cur, set[slot]);                        // step tt + 2 into the image of step tt
+            load_global(p_begin + (tt + 2 + PF) * BKW, set[slot]);                        // past the end: fully masked
+            mx += BKW;
+            mx -= mx >= W ? W : 0;
+            mask_edge(fa[nxt], mx);                           // the next step's fragment has long arrived
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {                     // an MFMA, then a few of the split / address / mask instructions, ...
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
+            }
+            __syncthreads();
+        };
+        int t = 0;
+        for (; t + PF <= nsteps; t += PF) unroll_iterations<PF>(iteration, t);
+        if (PF > 1) tail_iterations<PF - 1>(iteration, t, nsteps);
+    }
+    const bool direct = g.splits == 1;
+    float* dst = direct ? out : out + (size_t)blockIdx.z * ((size_t)g.Co * NC + g.Co);
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+        dst[(size_t)(m0 + wm + frag_row(lane, e)) * NC + n_base + frag_col(lane)] = acc[0][0][e];
+    if (bias_block) {
+        // the dY staging threads hold the sums of row kk of every step: fold the 16 rows through LDS
+        float* fold = reinterpret_cast<float*>(lds_raw);
+        __syncthreads();
+        if (role_a) *reinterpret_cast<f32x4*>(fold + kk * 68 + col) = bsum;
+        __syncthreads();
+        if (tid < 64) {
+            float tsum = 0.f;
+#pragma unroll
+            for (int k = 0; k < BKW; ++k) tsum += fold[k * 68 + tid];
+            if (direct) dbias[m0 + tid] = accumulate ? dbias[m0 + tid] + tsum : tsum;
+            else dst[(size_t)g.Co * NC + m0 + tid] = tsum;
+        }
+    }
+}
+
 // ---- weight gradient of a Linear layer over few rows (P <= 256: the M = 240 layers of the lane head) ------------------
 // dW[Co][Ci] (+)= dY^T X with the WHOLE reduction dimension staged in LDS at once: every global load of the workgroup is
 // in flight together (one memory latency instead of one per 16-row step - the generic loop needs ~2 us per step, and
@@ -1156,9 +1359,11 @@ PHNET_API int phnet_tune_force_conv_tile(int32_t bm, int32_t bn, int32_t splits)
 
 PHNET_API int phnet_tune_wgrad(int32_t allow_bm128, int32_t target_blocks)
 {
-    if (target_blocks < 1) return PHNET_ERR_ARG;
+    if (target_blocks == 0 || target_blocks < -1024) return PHNET_ERR_ARG;
     g_wgrad_bm128 = allow_bm128 & 1; g_wgrad_smallp = !(allow_bm128 & 2); g_wgrad_bkw = (allow_bm128 & 4) ? 32 : 16;
-    g_wgrad_target = target_blocks;
+    g_wgrad3 = !(allow_bm128 & 8);
+    if (target_blocks < 0) g_wgrad3_target = -target_blocks;      // workgroup target of the three-taps 3x3 kernel
+    else g_wgrad_target = target_blocks;
     return PHNET_OK;
 }
 
@@ -1289,12 +1494,27 @@ static long wgrad_splits(long P, long Co, long NC, int* bm_out)
     return splits;
 }
 
+// the three-taps kernel (conv_wgrad3x3_kernel): 3x3 / stride 1 / pad 1, channel counts in whole 64-tiles, bf16x3 arithmetic
+static bool wgrad3_applies(long P, int Hi, int Wi, int Ci, int Co, int R, int S, int stride, int pad)
+{
+    return g_wgrad3 && g_mma_mode == 3 && R == 3 && S == 3 && stride == 1 && pad == 1 && (Ci & 63) == 0 && (Co & 63) == 0 &&
+           Wi >= BK && P >= 64 && P * (long)max(Ci, Co) * 4 < 0x7fffffffL;
+}
+static long wgrad3_splits(long P, long Co, long Ci)
+{
+    const long tiles = (Co / 64) * (Ci / 64) * 3;
+    return max((long)1, min(min((long)256, P / 64), (g_wgrad3_target + tiles / 2) / tiles));
+}
+
 PHNET_API uint64_t phnet_conv2d_wgrad_workspace(int32_t N, int32_t Hi, int32_t Wi, int32_t Ci, int32_t Co,
                                                 int32_t R, int32_t S, int32_t stride, int32_t pad)
 {
     const long Ho = (Hi + 2 * pad - R) / stride + 1, Wo = (Wi + 2 * pad - S) / stride + 1;
     const long P = (long)N * Ho * Wo, NC = (long)R * S * Ci;
-    return (uint64_t)(wgrad_splits(P, Co, NC, nullptr) * (Co * NC + Co) * sizeof(float));
+    long splits = wgrad_splits(P, Co, NC, nullptr);
+    if (R == 3 && S == 3 && stride == 1 && pad == 1 && (Ci & 63) == 0 && (Co & 63) == 0)     // whichever kernel the call picks
+        splits = max(splits, min(min((long)256, max((long)1, P / 64)), (long)(1024 / ((Co / 64) * (Ci / 64) * 3) + 1)));
+    return (uint64_t)(splits * (Co * NC + Co) * sizeof(float));
 }
 
 // dw OHWI [Co][R][S][Ci] and (optionally) dbias [Co] = sum of dy over all pixels are overwritten (accumulate=0) or
@@ -1335,6 +1555,23 @@ PHNET_API int phnet_conv2d_wgrad(const float* dy, const float* x, float* dw, flo
         else
         hipLaunchKernelGGL((linear_wgrad_smallp_kernel<64, 64, 0>), dim3((unsigned)tiles), dim3(THREADS), lds, st, dy, x, dw, dbias,
                            (int)P, Co, Ci, dbias != nullptr, accumulate);
+        return phnet_launch_status();
+    }
+    if (wgrad3_applies(P, Hi, Wi, Ci, Co, R, S, stride, pad)) {
+        long splits = wgrad3_splits(P, Co, Ci);
+        const long row = (long)Co * NC + Co;
+        while (splits > 1 && (!workspace || (uint64_t)(splits * row * sizeof(float)) > ws_bytes)) --splits;
+        const long psteps = ceil_div64(P, BK);
+        g.splits = (int)splits;
+        g.pix_per_split = (int)(ceil_div64(psteps, splits) * BK);
+        float* out = splits > 1 ? (float*)workspace : dw;
+        dim3 grid((unsigned)((Co / 64) * (Ci / 64) * 3), 1, (unsigned)splits);
+        hipLaunchKernelGGL((conv_wgrad3x3_kernel<4>), grid, dim3(W3_THREADS), 0, st, dy, x, out, dbias, g, dbias != nullptr, accumulate);
+        if (splits > 1) {
+            const long nw = (long)Co * NC, nb = Co;
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div64((nw + nb) >> 2, 64)), dim3(256), 0, st,
+                               (const float*)workspace, dw, dbias, nw, nb, (int)splits, accumulate);
+        }
         return phnet_launch_status();
     }
     int bm = 64;

@@ -186,6 +186,9 @@ def conv2d_dgrad(dy, w, in_hw: Tuple[int, int], stride: int, pad: int, addend: O
     return dx
 
 
+_WGRAD3 = True          # mirrors csrc/conv.hip g_wgrad3 (kernel names of the bench's per-kernel accounting only)
+
+
 def conv2d_wgrad(dy, x, w_shape, stride: int, pad: int, dw: Optional[torch.Tensor] = None, accumulate: bool = False,
                  dbias: Optional[torch.Tensor] = None):
     """dW (and, when `dbias` is given, the bias gradient = column sums of dy) in one launch (+ reduce when split).
@@ -201,7 +204,10 @@ def conv2d_wgrad(dy, x, w_shape, stride: int, pad: int, dw: Optional[torch.Tenso
     ho, wo = conv_out_hw(hi, wi, r, s, stride, pad)
     smallp = (r == 1 and s == 1 and stride == 1 and pad == 0 and n * ho * wo <= 256 and
               ((co + 63) // 64) * ((ci + 63) // 64) < 400)                                # few-rows Linear kernel (csrc/conv.hip)
+    taps3 = (_MMA_MODE == 3 and r == 3 and s == 3 and stride == 1 and pad == 1 and ci % 64 == 0 and co % 64 == 0 and wi >= 16 and
+             n * ho * wo >= 64 and _WGRAD3)                                              # three-taps kernel (csrc/conv.hip)
     _timed_launch(lambda: (f"linear_wgrad_smallp_kernel<64, 64, {1 if _MMA_MODE == 1 else 0}>" if smallp
+                           else "conv_wgrad3x3_kernel<4>" if taps3
                            else f"conv_wgrad_kernel<{128 if (co >= 128 and (co < 256 or n * ho * wo > 8192)) else 64}, 64, {_MMA_MODE}, 16, {4 if _MMA_MODE == 3 else 1}, {'true' if _MMA_MODE == 3 else 'false'}>", 0),
                   2.0 * n * ho * wo * co * r * s * ci,
                   lambda: check(lib().phnet_conv2d_wgrad(_ptr(dy), _ptr(x), _ptr(dw), _ptr(dbias), n, hi, wi, ci, co, r, s, stride,

@@ -256,6 +256,45 @@ def test_conv_fwd_dgrad_wgrad_bf16x3(ops, bf16x3, case):
     close(dw, 2 * w.grad.permute(0, 2, 3, 1), 2e-5)
 
 
+@pytest.mark.parametrize("case", [(2, 16, 20, 64, 64), (3, 5, 17, 64, 128), (2, 7, 16, 128, 64), (1, 1, 70, 64, 64), (5, 20, 50, 256, 64),
+                                  (1, 10, 25, 512, 512), (4, 3, 23, 64, 64)])
+def test_wgrad_three_taps_kernel_vs_fp64(ops, bf16x3, case):
+    """conv_wgrad3x3_kernel (3x3 / stride 1 / pad 1, the three taps of a filter row from one staged pixel block): image rows
+    narrower / wider than the 16-pixel block, blocks that span image rows and frames, one-row images (every row is the top and
+    the bottom row), ragged pixel counts, bias gradient, accumulation - against fp64 at the tolerance of the generic kernel,
+    and against the generic kernel itself (phnet_tune_wgrad bit 3 switches the three-taps kernel off)."""
+    from phnet_amd._lib import lib
+    N, Hi, Wi, Ci, Co = case
+    torch.manual_seed(sum(case) + 11)
+    x = torch.randn(N, Ci, Hi, Wi, dtype=torch.float64)
+    w = (torch.randn(Co, Ci, 3, 3, dtype=torch.float64) / (Ci * 9) ** 0.5).requires_grad_(True)
+    ref = F.conv2d(x, w, None, stride=1, padding=1)
+    gy = torch.randn_like(ref)
+    ref.backward(gy)
+    xd, gyd = nhwc(x.float()), nhwc(gy.float())
+    want = w.grad.permute(0, 2, 3, 1)
+    shape = (Co, 3, 3, Ci)
+    db = torch.full((Co,), 7.0, device="cuda")
+    dw = ops.conv2d_wgrad(gyd, xd, shape, 1, 1, dbias=db)
+    close(dw, want, 2e-5)
+    close(db, gy.sum(dim=(0, 2, 3)), 2e-5)
+    ops.conv2d_wgrad(gyd, xd, shape, 1, 1, dw=dw, dbias=db, accumulate=True)
+    close(dw, 2 * want, 2e-5)
+    close(db, 2 * gy.sum(dim=(0, 2, 3)), 2e-5)
+    assert lib().phnet_tune_wgrad(1 | 8, 768) == 0                       # the generic kernel on the same operands
+    try:
+        dw_generic = ops.conv2d_wgrad(gyd, xd, shape, 1, 1)
+    finally:
+        assert lib().phnet_tune_wgrad(1, 768) == 0
+    close(dw_generic, want, 2e-5)
+    for target in (64, 1024):                                            # other splits of the pixel range, down to one step
+        assert lib().phnet_tune_wgrad(1, -target) == 0
+        try:
+            close(ops.conv2d_wgrad(gyd, xd, shape, 1, 1), want, 2e-5)
+        finally:
+            assert lib().phnet_tune_wgrad(1, -256) == 0
+
+
 def test_bf16x3_split_is_exact_on_adversarial_values(ops, bf16x3):
     """Operands chosen so that a two-term split would visibly lose bits: every mantissa bit set, magnitudes from 2^-100 to
     2^100 in one row, exact cancellation.  A 1x1 'convolution' with K = 64 against fp64."""

@@ -96,6 +96,15 @@ def main():
                     tw = timeit(lambda: K.conv2d_wgrad(gy, x, w.shape, st, pad))
                     print(f"   wgrad bm128={bm128 & 1} bkw={32 if bm128 & 4 else 16} target={target:5d}: {tw:7.1f} us {fl/tw/1e6:6.1f} TF/s")
             lib().phnet_tune_wgrad(1, 768)
+        if "--wgrad3" in sys.argv and R == 3 and st == 1:
+            for target in (128, 256, 384, 512, 768, 1024):               # workgroup target of the three-taps 3x3 kernel
+                lib().phnet_tune_wgrad(1, -target)
+                tw = timeit(lambda: K.conv2d_wgrad(gy, x, w.shape, st, pad))
+                print(f"   wgrad three-taps target={target:5d}: {tw:7.1f} us {fl/tw/1e6:6.1f} TF/s")
+            lib().phnet_tune_wgrad(1 | 8, 768)
+            tw = timeit(lambda: K.conv2d_wgrad(gy, x, w.shape, st, pad))
+            print(f"   wgrad generic kernel          : {tw:7.1f} us {fl/tw/1e6:6.1f} TF/s")
+            lib().phnet_tune_wgrad(1, -256); lib().phnet_tune_wgrad(1, 768)
         lib().phnet_tune_force_k_tile(0)
         for bm, bn, sp, tf, td in res:
             print(f"   tile {bm} splits {sp:2d}: fwd {tf:7.1f} us {fl/tf/1e6:6.1f} TF/s | dgrad {td:7.1f} us {fl/td/1e6:6.1f} TF/s")
