@@ -74,6 +74,7 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL over xGMI; gloo only for "
                                                       "functional rehearsals of the N>1 path on a single GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--wgrad-flags", type=int, default=None, help="tuning aid: hip_ops.tune_wgrad flags (8 = generic 3x3 weight-gradient kernel)")
     ap.add_argument("--force-dp", action="store_true",
                     help="rehearsal on ONE GPU: run the N > 1 code path (SyncBatchNorm containers, bucket reducer, RCCL collectives captured "
                          "in the graph) in a one-rank process group with the collectives forced on - what the data-parallel machinery "
@@ -177,6 +178,8 @@ def run_inference(args):
     from phnet_amd.libs.models.Router4OL import RouterOL
     from phnet_amd.synthetic import make_clip, spread_scores_
     hip_ops.set_mma_mode(args.mma)
+    if args.wgrad_flags is not None:
+        hip_ops.tune_wgrad(args.wgrad_flags)
     torch.cuda.set_device(0)
     torch.manual_seed(0)
     clips, T, H, W = 32, args.frames, args.height, args.width
@@ -250,6 +253,8 @@ def main():
     from phnet_amd.synthetic import make_clip, make_targets
 
     hip_ops.set_mma_mode(args.mma)
+    if args.wgrad_flags is not None:
+        hip_ops.tune_wgrad(args.wgrad_flags)
     torch.manual_seed(3407)
     cfg = make_cfg(img_h=args.height, img_w=args.width, arch=args.arch)
     model = RouterOL(cfg, Criterion4OL(cfg)).to(dev).train()

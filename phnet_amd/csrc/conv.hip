@@ -825,19 +825,23 @@ __global__ __launch_bounds__(THREADS) void conv_wgrad_kernel(
 // bf16x3 arithmetic, buffer loads; Ci, Co multiples of 64.
 constexpr int W3_THREADS = 768;
 int g_wgrad3 = 1, g_wgrad3_target = 256;                     // tuning aids (phnet_tune_wgrad: bit 3 of arg 0 switches it off; a negative
-                                                             // second argument sets its workgroup target)
-template <int PF>
+int g_wgrad3_bkw = 16;                                       // second argument sets its workgroup target, bit 4 selects 32-pixel steps)
+template <int BKW> struct Wgrad3Lds {
+    static constexpr int ROWS = BKW + 2;                     // X rows of a step: pixels pt-1 .. pt+BKW of the shifted image row
+    static constexpr int PITCH = KStridedPlanes<64, BK>::PITCH;      // 192 bytes: 64 bf16 + pad (igemm.h)
+    static constexpr int PLANE = ROWS * PITCH, IMG = 3 * PLANE;      // both operands use the ROWS-row image (dY leaves two rows unused)
+    static constexpr int BYTES = 6 * IMG + 2 * PLANE + 512;          // 3 buffers x 2 operands + a dump area for the idle staging lanes
+};
+template <int PF, int BKW>
 __global__ __launch_bounds__(W3_THREADS) void conv_wgrad3x3_kernel(
     const float* __restrict__ dY, const float* __restrict__ X, float* __restrict__ out, float* __restrict__ dbias,
     WgradShape g, int want_bias, int accumulate)
 {
-    constexpr int BKW = BK;                                  // 16 pixels per K step
-    constexpr int ROWS = BKW + 2;                            // X rows of a step: pixels pt-1 .. pt+16 of the shifted image row
-    constexpr int PITCH = KStridedPlanes<64, BKW>::PITCH;    // 192 bytes: 64 bf16 + pad (igemm.h)
-    constexpr int PLANE = ROWS * PITCH, IMG = 3 * PLANE;     // both operands use the 18-row image (dY leaves two rows unused)
-    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[4 * IMG + 2 * PLANE + 512];    // + a dump area (one slot per plane) for the idle staging lanes
-    unsigned char* A3 = lds_raw;                             // [buf][plane][row][col]
-    unsigned char* B3 = lds_raw + 2 * IMG;
+    constexpr int NSUB = BKW / BK;                           // 16-pixel MFMA sub-steps per K step
+    typedef Wgrad3Lds<BKW> L;
+    constexpr int PITCH = L::PITCH, PLANE = L::PLANE, IMG = L::IMG;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];               // [buf 0..2][dY | X][plane][row][col], dump
+    static_assert(PF % 2 == 0 && (NSUB == 1 || NSUB == 2), "fragment parity is read off the ring slot");
 
     const int NC = 9 * g.Ci, W = g.Wi, H = g.Hi;
     const int P = g.N * H * W;
@@ -851,48 +855,61 @@ __global__ __launch_bounds__(W3_THREADS) void conv_wgrad3x3_kernel(
     const int tg = wave >> 2, dx = tg - 1;                   // tap group of this wave
     const int wm = ((wave >> 1) & 1) * 32, wn = (wave & 1) * 32;
 
-    // ---- staging roles (wave-uniform): waves 0-3 dY, waves 4-7 X rows 0-15, wave 8 (first half) X rows 16-17 ----
-    const bool role_a = wave < 4;
-    const int st = tid - (role_a ? 0 : 256);
-    const int kk = st >> 4, col = (st & 15) * 4;             // row of the image, first of 4 columns
-    const bool active = wave < 8 || (wave == 8 && lane < 32);
+    // ---- staging roles (wave-uniform): waves 0-3 dY, waves 4-7 X rows 0..BKW-1 (row kk + 16 i each), wave 8 (first half) the
+    // two X rows BKW, BKW+1 ----
+    const bool role_a = wave < 4, halo = wave == 8;
+    const int st = tid - (role_a ? 0 : (halo ? 512 : 256));
+    const int kk = (st >> 4) + (halo ? BKW : 0), col = (st & 15) * 4;                     // first row of the image, first of 4 columns
     const float* src = role_a ? dY : X;
     const int cs = role_a ? g.Co : g.Ci;                     // channels of the source tensor
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (int)min((long)P * cs * 4, (long)0x7fffffff), 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
-    // dY: element (pt + kk, m0 + col); X: aligned pixel t = pt - 1 + kk, source pixel t + dy * W, channel c0 + col
-    const int off_c = role_a ? (kk * cs + m0 + col) * 4 : ((kk - 1 + dy * W) * cs + c0 + col) * 4;
-    int t_cur = p_begin + kk - (role_a ? 0 : 1);             // dY: the pixel; X: the aligned pixel
-    int t_x, t_y;
-    {
-        const int tt = t_cur + W * H;                        // >= 0; same (x, y) as t_cur
+    bool active[NSUB];
+    int off_c[NSUB], t_cur[NSUB], t_x[NSUB], t_y[NSUB], st_off[NSUB];
+#pragma unroll
+    for (int i = 0; i < NSUB; ++i) {
+        const int row = kk + 16 * i;
+        active[i] = wave < 8 || (halo && lane < 32 && i == 0);
+        // dY: element (pt + row, m0 + col); X: aligned pixel t = pt - 1 + row, source pixel t + dy * W, channel c0 + col
+        off_c[i] = role_a ? (row * cs + m0 + col) * 4 : ((row - 1 + dy * W) * cs + c0 + col) * 4;
+        t_cur[i] = p_begin + row - (role_a ? 0 : 1);         // dY: the pixel; X: the aligned pixel
+        const int tt = t_cur[i] + W * H;                     // >= 0; same (x, y) as t_cur
         const int rowi = tt / W;
-        t_x = tt - rowi * W;
-        t_y = rowi % H;
+        t_x[i] = tt - rowi * W;
+        t_y[i] = rowi % H;
+        // lanes without a staging job write their (zero) chunk into the dump area behind the images: the loop body stays one
+        // basic block, so that the scheduler can interleave the split with the MFMAs
+        st_off[i] = active[i] ? (role_a ? 0 : IMG) + row * PITCH + col * 2 : 6 * IMG + lane * 8;
     }
-    f32x4 set[PF];
+    f32x4 set[PF][NSUB];
     f32x4 bsum = f32x4{0.f, 0.f, 0.f, 0.f};
     const bool bias_block = want_bias && ct == 0 && dyi == 0;
-    // loads the K step that starts at pixel pt; MUST be called with pt = p_begin, p_begin + 16, ... in order (branch-free)
-    auto load_global = [&](int pt, f32x4& reg) {
-        const bool ok_a = t_cur < p_end;
-        const bool ok_b = (unsigned)t_cur < (unsigned)P && (unsigned)(t_y + dy) < (unsigned)H;
-        const bool ok = active && (role_a ? ok_a : ok_b);
-        reg = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok ? off_c + pt * cs * 4 : (int)OOB, 0, 0));
-        t_cur += BKW;
-        t_x += BKW;
-        const int wx = t_x >= W;
-        t_x -= wx ? W : 0;
-        t_y += wx;
-        t_y = t_y == H ? 0 : t_y;
-    };
-    // branch-free (the loop body stays one basic block, so that the scheduler can interleave the split with the MFMAs): lanes
-    // without a staging job write their (zero) chunk into a dump slot behind the images
     const float bflag = (role_a && bias_block) ? 1.f : 0.f;
-    const int st_off = active ? (role_a ? 0 : 2 * IMG) + kk * PITCH + col * 2 : 4 * IMG + lane * 8;
-    auto store_lds = [&](int buf, const f32x4& v) {
-        bsum += v * bflag;
-        store_split3<PLANE>(lds_raw, st_off + (active ? buf * IMG : 0), v);
+    // loads the K step that starts at pixel pt; MUST be called with pt = p_begin, p_begin + BKW, ... in order (branch-free)
+    auto load_global = [&](int pt, f32x4 (&reg)[NSUB]) {
+#pragma unroll
+        for (int i = 0; i < NSUB; ++i) {
+            const bool ok_a = t_cur[i] < p_end;
+            const bool ok_b = (unsigned)t_cur[i] < (unsigned)P && (unsigned)(t_y[i] + dy) < (unsigned)H;
+            const bool ok = active[i] && (role_a ? ok_a : ok_b);
+            reg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok ? off_c[i] + pt * cs * 4 : (int)OOB, 0, 0));
+            t_cur[i] += BKW;
+            t_x[i] += BKW;
+#pragma unroll
+            for (int r = 0; r < NSUB; ++r) {                 // W >= 16: at most NSUB row wraps per step
+                const int wx = t_x[i] >= W;
+                t_x[i] -= wx ? W : 0;
+                t_y[i] += wx;
+                t_y[i] = t_y[i] == H ? 0 : t_y[i];
+            }
+        }
+    };
+    auto store_lds = [&](int buf_off, const f32x4 (&v)[NSUB]) {
+#pragma unroll
+        for (int i = 0; i < NSUB; ++i) {
+            bsum += v[i] * bflag;
+            store_split3<PLANE>(lds_raw, st_off[i] + (active[i] ? buf_off : 0), v[i]);
+        }
     };
 
     const bool from_old = g.splits == 1 && accumulate;
@@ -906,36 +923,36 @@ __global__ __launch_bounds__(W3_THREADS) void conv_wgrad3x3_kernel(
     }
 
     if (p_begin < p_end) {
-        // Software pipeline over the K steps (all 12 waves of the CU's one workgroup run in lock-step, so nothing else hides an
-        // LDS round trip): in iteration t the fragments of step t+1 are fetched from LDS into a second register set, step t is
-        // multiplied from the set fetched an iteration ago, step t+2 moves from its ring slot into the LDS image step t has
-        // just left, and the ring slot takes step t+2+PF.  One barrier per step.
+        // Software pipeline over the 16-pixel sub-steps (all 12 waves of the CU's one workgroup run in lock-step, so nothing
+        // else hides an LDS round trip): while sub-step s is multiplied, the fragments of sub-step s+1 - the next one of this
+        // K step, or the first one of the next K step - travel from LDS into the other register set.  Three LDS buffers: in
+        // iteration t step t is read, step t+1 is read (its first sub-step) and step t+2 is written (into the buffer step t-1
+        // left before the last barrier); the ring slot it came from takes step t+2+PF.  One barrier per K step.
         const int nsteps = (p_end - p_begin + BKW - 1) / BKW;
-        int mx = p_begin % W;                                // x of the first pixel of the step being multiplied
-        static_assert(PF % 2 == 0, "the step parity is read off the ring slot");
+        int mx = p_begin % W;                                // image column of the first pixel of the sub-step whose fragment is masked next
 #pragma unroll
         for (int d = 0; d < PF; ++d) load_global(p_begin + d * BKW, set[d]);
         store_lds(0, set[0]);
         load_global(p_begin + PF * BKW, set[0]);
-        store_lds(1, set[1 % PF]);
+        store_lds(2 * IMG, set[1 % PF]);
         load_global(p_begin + (PF + 1) * BKW, set[1 % PF]);
         __syncthreads();
         Frag3 fa[2], fb[2];
-        const unsigned char* a_src = A3 + wm * 2;
-        const unsigned char* b_src = B3 + (dx + 1) * PITCH + wn * 2;
-        {
-            Frag3 (&a0)[1] = *reinterpret_cast<Frag3 (*)[1]>(&fa[0]);
-            Frag3 (&b0)[1] = *reinterpret_cast<Frag3 (*)[1]>(&fb[0]);
-            read_kstrided3<1, PITCH, PLANE>(a_src, lane, 0, a0);
-            read_kstrided3<1, PITCH, PLANE>(b_src, lane, 0, b0);
-        }
+        const unsigned char* a_src = lds_raw + wm * 2;
+        const unsigned char* b_src = lds_raw + IMG + (dx + 1) * PITCH + wn * 2;
+        auto read_frags = [&](int buf_off, int ks, Frag3& a, Frag3& b) {
+            Frag3 (&a1)[1] = *reinterpret_cast<Frag3 (*)[1]>(&a);
+            Frag3 (&b1)[1] = *reinterpret_cast<Frag3 (*)[1]>(&b);
+            read_kstrided3<1, PITCH, PLANE>(a_src + buf_off, lane, ks, a1);
+            read_kstrided3<1, PITCH, PLANE>(b_src + buf_off, lane, ks, b1);
+        };
         const int h8 = (lane >> 5) * 8;
-        // clears, in a dY fragment, the pixel of the block starting at image column x0 whose tap dx leaves the image row
-        // (this lane holds k = h8 .. h8 + 7; no such pixel: element index -1)
-        auto mask_edge = [&](Frag3& a, int x0) {
-            const int ke = dx < 0 ? (x0 == 0 ? 0 : W - x0) : W - 1 - x0;
-            const int j = (dx != 0 && ke < BKW) ? ke - h8 : -1;
-            const int ji = j >> 1;                            // register of the element (negative: none)
+        // clears, in a dY fragment, pixel ke of its 16-pixel block - the one whose tap dx leaves the image row (this lane holds
+        // k = h8 .. h8 + 7).  Under a wave-uniform branch: the dx = 0 group never needs it, the others once per image row
+        // (built unconditionally, these ~26 vector instructions per sub-step ate what the shared staging saves)
+        auto mask_edge = [&](Frag3& a, int ke) {
+            const int j = ke - h8;
+            const int ji = j >> 1;                            // register of the element (other half wave: none)
             const unsigned wmask = (j & 1) ? 0x0000ffffu : 0xffff0000u;
             typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
             u32x4 m;
@@ -945,30 +962,35 @@ __global__ __launch_bounds__(W3_THREADS) void conv_wgrad3x3_kernel(
             a.mid = __builtin_bit_cast(bf16x8, __builtin_bit_cast(u32x4, a.mid) & m);
             a.lo = __builtin_bit_cast(bf16x8, __builtin_bit_cast(u32x4, a.lo) & m);
         };
-        mask_edge(fa[0], mx);
+        read_frags(0, 0, fa[0], fb[0]);
+        int o_cur = 0, o_nxt = 2 * IMG, o_st = 4 * IMG;       // byte offsets of the buffers of steps t, t+1, t+2
         auto iteration = [&](auto U, int tt) {
             constexpr int u = decltype(U)::value;             // tt % PF
-            constexpr int cur = u & 1, nxt = cur ^ 1, slot = (u + 2) % PF;
-            {
-                Frag3 (&an)[1] = *reinterpret_cast<Frag3 (*)[1]>(&fa[nxt]);
-                Frag3 (&bn)[1] = *reinterpret_cast<Frag3 (*)[1]>(&fb[nxt]);
-                read_kstrided3<1, PITCH, PLANE>(a_src + nxt * IMG, lane, 0, an);
-                read_kstrided3<1, PITCH, PLANE>(b_src + nxt * IMG, lane, 0, bn);
-            }
-            Frag3 (&a)[1] = *reinterpret_cast<Frag3 (*)[1]>(&fa[cur]);
-            Frag3 (&b)[1] = *reinterpret_cast<Frag3 (*)[1]>(&fb[cur]);
-            mma3_step<1, 1>(a, b, acc);
-            store_lds(cur, set[slot]);                        // step tt + 2 into the image of step tt
-            load_global(p_begin + (tt + 2 + PF) * BKW, set[slot]);                        // past the end: fully masked
-            mx += BKW;
-            mx -= mx >= W ? W : 0;
-            mask_edge(fa[nxt], mx);                           // the next step's fragment has long arrived
+            constexpr int slot = (u + 2) % PF;
 #pragma unroll
-            for (int i = 0; i < 6; ++i) {                     // an MFMA, then a few of the split / address / mask instructions, ...
+            for (int ks = 0; ks < NSUB; ++ks) {
+                const int cur = (u * NSUB + ks) & 1, nxt = cur ^ 1;
+                {
+                    const int ke = dx < 0 ? (mx == 0 ? 0 : W - mx) : W - 1 - mx;          // mx: image column of this sub-step's first pixel
+                    if (dx != 0 && ke < BK) mask_edge(fa[cur], ke);
+                    mx += BK;
+                    mx -= mx >= W ? W : 0;
+                }
+                if (ks + 1 < NSUB) read_frags(o_cur, ks + 1, fa[nxt], fb[nxt]);
+                else read_frags(o_nxt, 0, fa[nxt], fb[nxt]);
+                Frag3 (&a)[1] = *reinterpret_cast<Frag3 (*)[1]>(&fa[cur]);
+                Frag3 (&b)[1] = *reinterpret_cast<Frag3 (*)[1]>(&fb[cur]);
+                mma3_step<1, 1>(a, b, acc);
+            }
+            store_lds(o_st, set[slot]);                       // step tt + 2
+            load_global(p_begin + (tt + 2 + PF) * BKW, set[slot]);                        // past the end: fully masked
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {                     // an MFMA, then a few of the split / address instructions, ...
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
             }
             __syncthreads();
+            const int o = o_cur; o_cur = o_nxt; o_nxt = o_st; o_st = o;
         };
         int t = 0;
         for (; t + PF <= nsteps; t += PF) unroll_iterations<PF>(iteration, t);
@@ -980,7 +1002,7 @@ __global__ __launch_bounds__(W3_THREADS) void conv_wgrad3x3_kernel(
     for (int e = 0; e < 16; ++e)
         dst[(size_t)(m0 + wm + frag_row(lane, e)) * NC + n_base + frag_col(lane)] = acc[0][0][e];
     if (bias_block) {
-        // the dY staging threads hold the sums of row kk of every step: fold the 16 rows through LDS
+        // the dY staging threads hold the sums of rows kk + 16 i of every step: fold the 16 row classes through LDS
         float* fold = reinterpret_cast<float*>(lds_raw);
         __syncthreads();
         if (role_a) *reinterpret_cast<f32x4*>(fold + kk * 68 + col) = bsum;
@@ -988,7 +1010,7 @@ __global__ __launch_bounds__(W3_THREADS) void conv_wgrad3x3_kernel(
         if (tid < 64) {
             float tsum = 0.f;
 #pragma unroll
-            for (int k = 0; k < BKW; ++k) tsum += fold[k * 68 + tid];
+            for (int k = 0; k < BK; ++k) tsum += fold[k * 68 + tid];
             if (direct) dbias[m0 + tid] = accumulate ? dbias[m0 + tid] + tsum : tsum;
             else dst[(size_t)g.Co * NC + m0 + tid] = tsum;
         }
@@ -1362,6 +1384,7 @@ PHNET_API int phnet_tune_wgrad(int32_t allow_bm128, int32_t target_blocks)
     if (target_blocks == 0 || target_blocks < -1024) return PHNET_ERR_ARG;
     g_wgrad_bm128 = allow_bm128 & 1; g_wgrad_smallp = !(allow_bm128 & 2); g_wgrad_bkw = (allow_bm128 & 4) ? 32 : 16;
     g_wgrad3 = !(allow_bm128 & 8);
+    g_wgrad3_bkw = (allow_bm128 & 16) ? 32 : 16;
     if (target_blocks < 0) g_wgrad3_target = -target_blocks;      // workgroup target of the three-taps 3x3 kernel
     else g_wgrad_target = target_blocks;
     return PHNET_OK;
@@ -1561,12 +1584,23 @@ PHNET_API int phnet_conv2d_wgrad(const float* dy, const float* x, float* dw, flo
         long splits = wgrad3_splits(P, Co, Ci);
         const long row = (long)Co * NC + Co;
         while (splits > 1 && (!workspace || (uint64_t)(splits * row * sizeof(float)) > ws_bytes)) --splits;
-        const long psteps = ceil_div64(P, BK);
+        const int bkw = g_wgrad3_bkw == 16 ? 16 : 32;
+        const long psteps = ceil_div64(P, bkw);
         g.splits = (int)splits;
-        g.pix_per_split = (int)(ceil_div64(psteps, splits) * BK);
+        g.pix_per_split = (int)(ceil_div64(psteps, splits) * bkw);
         float* out = splits > 1 ? (float*)workspace : dw;
         dim3 grid((unsigned)((Co / 64) * (Ci / 64) * 3), 1, (unsigned)splits);
-        hipLaunchKernelGGL((conv_wgrad3x3_kernel<4>), grid, dim3(W3_THREADS), 0, st, dy, x, out, dbias, g, dbias != nullptr, accumulate);
+        static bool attr = false;
+        if (!attr) {
+            if (hipFuncSetAttribute((const void*)conv_wgrad3x3_kernel<4, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, Wgrad3Lds<16>::BYTES) != hipSuccess ||
+                hipFuncSetAttribute((const void*)conv_wgrad3x3_kernel<4, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, Wgrad3Lds<32>::BYTES) != hipSuccess)
+                return PHNET_ERR_LAUNCH;
+            attr = true;
+        }
+        if (bkw == 16)
+            hipLaunchKernelGGL((conv_wgrad3x3_kernel<4, 16>), grid, dim3(W3_THREADS), Wgrad3Lds<16>::BYTES, st, dy, x, out, dbias, g, dbias != nullptr, accumulate);
+        else
+            hipLaunchKernelGGL((conv_wgrad3x3_kernel<4, 32>), grid, dim3(W3_THREADS), Wgrad3Lds<32>::BYTES, st, dy, x, out, dbias, g, dbias != nullptr, accumulate);
         if (splits > 1) {
             const long nw = (long)Co * NC, nb = Co;
             hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div64((nw + nb) >> 2, 64)), dim3(256), 0, st,

@@ -207,7 +207,7 @@ def conv2d_wgrad(dy, x, w_shape, stride: int, pad: int, dw: Optional[torch.Tenso
     taps3 = (_MMA_MODE == 3 and r == 3 and s == 3 and stride == 1 and pad == 1 and ci % 64 == 0 and co % 64 == 0 and wi >= 16 and
              n * ho * wo >= 64 and _WGRAD3)                                              # three-taps kernel (csrc/conv.hip)
     _timed_launch(lambda: (f"linear_wgrad_smallp_kernel<64, 64, {1 if _MMA_MODE == 1 else 0}>" if smallp
-                           else "conv_wgrad3x3_kernel<4>" if taps3
+                           else "conv_wgrad3x3_kernel<4, 16>" if taps3
                            else f"conv_wgrad_kernel<{128 if (co >= 128 and (co < 256 or n * ho * wo > 8192)) else 64}, 64, {_MMA_MODE}, 16, {4 if _MMA_MODE == 3 else 1}, {'true' if _MMA_MODE == 3 else 'false'}>", 0),
                   2.0 * n * ho * wo * co * r * s * ci,
                   lambda: check(lib().phnet_conv2d_wgrad(_ptr(dy), _ptr(x), _ptr(dw), _ptr(dbias), n, hi, wi, ci, co, r, s, stride,
@@ -925,6 +925,14 @@ def tower_chain_fwd(x, params, head_out, priors, ys, img_w, img_h):
 
 
 DEFAULT_MMA = "bf16x3"
+
+
+def tune_wgrad(flags: int = 1, target: int = 768) -> None:
+    """Benchmark aid (process-global): phnet_tune_wgrad - bit 3 of `flags` switches the three-taps 3x3 weight-gradient kernel off,
+    bit 4 gives it 32-pixel steps; a negative `target` is ITS workgroup target, a positive one the generic kernel's."""
+    global _WGRAD3
+    check(lib().phnet_tune_wgrad(flags, target), "phnet_tune_wgrad")
+    _WGRAD3 = not (flags & 8)
 
 
 def set_mma_mode(mode: str) -> None:

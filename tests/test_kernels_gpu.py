@@ -287,8 +287,8 @@ def test_wgrad_three_taps_kernel_vs_fp64(ops, bf16x3, case):
     finally:
         assert lib().phnet_tune_wgrad(1, 768) == 0
     close(dw_generic, want, 2e-5)
-    for target in (64, 1024):                                            # other splits of the pixel range, down to one step
-        assert lib().phnet_tune_wgrad(1, -target) == 0
+    for flags, target in ((1, 64), (1, 1024), (1 | 16, 256), (1 | 16, 1024)):      # other splits of the pixel range, down to one step;
+        assert lib().phnet_tune_wgrad(flags, -target) == 0                   # bit 4: 32-pixel instead of 16-pixel steps
         try:
             close(ops.conv2d_wgrad(gyd, xd, shape, 1, 1), want, 2e-5)
         finally:

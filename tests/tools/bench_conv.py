@@ -97,10 +97,10 @@ def main():
                     print(f"   wgrad bm128={bm128 & 1} bkw={32 if bm128 & 4 else 16} target={target:5d}: {tw:7.1f} us {fl/tw/1e6:6.1f} TF/s")
             lib().phnet_tune_wgrad(1, 768)
         if "--wgrad3" in sys.argv and R == 3 and st == 1:
-            for target in (128, 256, 384, 512, 768, 1024):               # workgroup target of the three-taps 3x3 kernel
-                lib().phnet_tune_wgrad(1, -target)
+            for flags, target in ((1, 256), (1, 512), (1 | 16, 256), (1 | 16, 512)):    # workgroup target of the three-taps 3x3 kernel; bit 4: 16-pixel steps
+                lib().phnet_tune_wgrad(flags, -target)
                 tw = timeit(lambda: K.conv2d_wgrad(gy, x, w.shape, st, pad))
-                print(f"   wgrad three-taps target={target:5d}: {tw:7.1f} us {fl/tw/1e6:6.1f} TF/s")
+                print(f"   wgrad three-taps {32 if flags & 16 else 16}-pixel steps target={target:5d}: {tw:7.1f} us {fl/tw/1e6:6.1f} TF/s")
             lib().phnet_tune_wgrad(1 | 8, 768)
             tw = timeit(lambda: K.conv2d_wgrad(gy, x, w.shape, st, pad))
             print(f"   wgrad generic kernel          : {tw:7.1f} us {fl/tw/1e6:6.1f} TF/s")
