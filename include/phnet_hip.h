@@ -161,6 +161,19 @@ int phnet_preprocess_u8(const uint8_t* frames, float* out, uint8_t* out_u8,
                         int32_t T, int32_t H0, int32_t W0, int32_t crop_top, int32_t out_h, int32_t out_w, int32_t flip,
                         int32_t layout, const float* mean3_host, const float* std3_host, void* stream);
 
+/* ---- lane IoU of the CULane-style evaluator: replaces LaneCompare::get_lane_similarity's two
+ * cv::Mat canvases + cv::line + cv::sum (evaluation/culane/src/lane_compare.cpp:11-57).  A lane is a bit mask
+ * [height][ceil(width/32)] uint32 in device memory.  phnet_lane_raster ORs thick segments into masks the caller zeroed: segs
+ * [n_segs][5] int32 = (x0, y0, x1, y1, lane) with end points inside +-8192 (the cvRound'ed points of the interpolated lane);
+ * a pixel is set iff its centre lies within lane_width/2 of the segment (exact integer test; parity against OpenCV's scan
+ * conversion of the same segment unpinned - see oracle/culane_cpu.py).  phnet_lane_mask_stats adds the set bits of every mask to
+ * area[n_lanes] and of masks[pairs[p][0]] & masks[pairs[p][1]] to inter[n_pairs] (int64, zeroed by the caller).
+ * height, width <= 4096; lane_width <= 256; n_lanes + n_pairs <= 65535. ---- */
+int phnet_lane_raster(const int32_t* segs, int64_t n_segs, uint32_t* masks, int32_t n_lanes, int32_t height, int32_t width,
+                      int32_t lane_width, void* stream);
+int phnet_lane_mask_stats(const uint32_t* masks, int32_t n_lanes, int32_t height, int32_t width, const int32_t* pairs,
+                          int32_t n_pairs, int64_t* area, int64_t* inter, void* stream);
+
 /* ---- MaxPool2d(3,2,1): libs/models/resnet.py:217,297 ---- */
 int phnet_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* argmax, int32_t N, int32_t Hi, int32_t Wi, int32_t C, void* stream);
 int phnet_maxpool3x3s2_bwd(const float* dy, const uint8_t* argmax, float* dx, int32_t N, int32_t Hi, int32_t Wi, int32_t C, void* stream);

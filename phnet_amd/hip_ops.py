@@ -927,6 +927,34 @@ def tower_chain_fwd(x, params, head_out, priors, ys, img_w, img_h):
 DEFAULT_MMA = "bf16x3"
 
 
+def lane_raster(segs, n_lanes: int, height: int, width: int, lane_width: int):
+    """Bit masks [n_lanes][height][ceil(width/32)] (int32 words) of the thick poly-lines: segs [S][5] int32 = (x0, y0, x1, y1, lane)
+    (csrc/lane_iou.hip; the evaluator's cv::line canvases, evaluation/culane/src/lane_compare.cpp:17-49)."""
+    _req(segs, torch.int32, "segs")
+    assert segs.dim() == 2 and segs.shape[1] == 5
+    masks = torch.zeros((n_lanes, height, (width + 31) // 32), dtype=torch.int32, device=segs.device)
+    check(lib().phnet_lane_raster(_ptr(segs), segs.shape[0], _ptr(masks), n_lanes, height, width, lane_width, _stream()), "phnet_lane_raster")
+    return masks
+
+
+def lane_mask_stats(masks, pairs, width: int):
+    """(area [n_lanes], inter [n_pairs]) int64: set bits of every mask and of masks[pairs[p, 0]] & masks[pairs[p, 1]]
+    (lane_compare.cpp:51-55: cv::sum of the canvases and of their product)."""
+    _req(masks, torch.int32, "masks"); _req(pairs, torch.int32, "pairs")
+    n_lanes, height = masks.shape[0], masks.shape[1]
+    assert masks.shape[2] == (width + 31) // 32 and pairs.dim() == 2 and pairs.shape[1] == 2
+    area = torch.zeros(n_lanes, dtype=torch.int64, device=masks.device)
+    inter = torch.zeros(pairs.shape[0], dtype=torch.int64, device=masks.device)
+    check(lib().phnet_lane_mask_stats(_ptr(masks), n_lanes, height, width, _ptr(pairs), pairs.shape[0], _ptr(area), _ptr(inter),
+                                      _stream()), "phnet_lane_mask_stats")
+    return area, inter
+
+
+def lane_mask_iou(segs, n_lanes: int, pairs, height: int, width: int, lane_width: int):
+    """Areas of the drawn lanes and the pairwise intersections the IoU matrices need, two launches."""
+    return lane_mask_stats(lane_raster(segs, n_lanes, height, width, lane_width), pairs, width)
+
+
 def tune_wgrad(flags: int = 1, target: int = 768) -> None:
     """Benchmark aid (process-global): phnet_tune_wgrad - bit 3 of `flags` switches the three-taps 3x3 weight-gradient kernel off,
     bit 4 gives it 32-pixel steps; a negative `target` is ITS workgroup target, a positive one the generic kernel's."""

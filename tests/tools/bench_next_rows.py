@@ -2,6 +2,7 @@
 kernel, the CPU oracle timed beside it on the host cores).  Prints ONE JSON object; profiles/r02_next_rows.json keeps a copy.
   f1  Router4OLV2 family (what testOLV3.py runs): inference clips/s of a 5-frame 320x800 clip, ResNet-18, one hipGraph per clip
   f2  criterion variants loss4OL / loss4OLV2 (+ one-to-many assignment): per-frame time on the device vs the CPU oracle (scipy)
+  f3  CULane-style evaluator: images/s of the whole evaluation (host parsing / splines / matching + device raster and bit counts)
   f4  input pre-processing: frames/s and HBM GB/s of the one-launch crop / bicubic resize / normalise kernel"""
 import json
 import os
@@ -136,6 +137,47 @@ def main():
                       "note": "device: HIP assignment kernel(s) + tensor-op loss under autograd, no host sync; eager = bound by the host's "
                               "operator dispatch (~450 tiny launches), hipGraph = how a captured training step runs it; bound: launch latency"}
     out["f2_criterion_variants"] = crit
+
+    # ---- 8(f) rank 3: the CULane-style evaluator on synthetic OpenLane-V sized label files (1280 x 1920 canvas, lane width 30) ----
+    import tempfile
+    from phnet_amd.evaluation import culane as EV
+    from oracle import culane_cpu as EO
+    rng = np.random.default_rng(0)
+    with tempfile.TemporaryDirectory() as tmp:
+        os.makedirs(tmp + "/a/v"); os.makedirs(tmp + "/d/v")
+        names = []
+        n_img = 256
+        for i in range(n_img):
+            lanes = []
+            for _ in range(4):
+                ys = np.linspace(1270, 640, 16)
+                lanes.append(np.stack([rng.uniform(300, 1600) + np.cumsum(rng.normal(0, 15, 16)), ys], 1))
+            for d, noise in (("a", 0.0), ("d", 8.0)):
+                with open(f"{tmp}/{d}/v/{i:04d}.lines.txt", "w") as fh:
+                    fh.write("".join(" ".join(f"{x + rng.normal(0, noise):.1f} {y:.1f}" for x, y in l) + " \n" for l in lanes))
+            names.append(f"/v/{i:04d}.jpg")
+        EV.evaluate(tmp + "/a", tmp + "/d", names[:8], 1920, 1280, 30, 0.5)                    # warm-up
+        t0 = time.perf_counter()
+        res = EV.evaluate(tmp + "/a", tmp + "/d", names, 1920, 1280, 30, 0.5)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        images = [(EV.read_lane_file(f"{tmp}/a{n[:-4]}.lines.txt"), EV.read_lane_file(f"{tmp}/d{n[:-4]}.lines.txt")) for n in names[:64]]
+        segs = [np.concatenate([EV.lane_segments(l), np.full((len(EV.lane_segments(l)), 1), k, np.int32)], 1)
+                for k, l in enumerate(l for im in images for l in im[0] + im[1])]
+        seg_t = torch.from_numpy(np.concatenate(segs)).cuda()
+        pairs = torch.tensor([(8 * i + a, 8 * i + 4 + b) for i in range(64) for a in range(4) for b in range(4)], dtype=torch.int32).cuda()
+        from phnet_amd import hip_ops as HK
+        dk = timed(lambda: HK.lane_mask_iou(seg_t, 512, pairs, 1280, 1920, 30), 10)
+        t0 = time.perf_counter()
+        ref = EO.evaluate(tmp + "/a", tmp + "/d", names[:6], 1920, 1280, 30, 0.5)
+        dc = (time.perf_counter() - t0) / 6
+    out["f3_culane_evaluator"] = {
+        "images_per_s": round(n_img / dt, 1), "workload": f"{n_img} frames, 4 annotated + 4 detected 16-point lanes each, 1280x1920 canvas, lane width 30, IoU 0.5",
+        "F1": res["Fmeasure"], "miou": round(res["miou"], 4),
+        "device_ms_per_64_images": round(dk * 1e3, 3),
+        "device_note": "phnet_lane_raster (512 lanes, 750 segments each, one workgroup per segment) + phnet_lane_mask_stats (512 areas + 1024 "
+                       "intersections over 512 x 307 KB bit masks); the rest of the wall time is the host: label parsing, splines, matching",
+        "cpu_oracle_images_per_s": round(1.0 / dc, 2), "bound": "host text parsing + numpy splines; device part HBM (bit masks)"}
     print(json.dumps(out))
 
 
