@@ -74,6 +74,7 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL over xGMI; gloo only for "
                                                       "functional rehearsals of the N>1 path on a single GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--tune-k-tile", type=int, default=None, help="tuning aid: phnet_tune_force_k_tile code (-5 = generic 3x3 forward / dgrad kernel)")
     ap.add_argument("--wgrad-flags", type=int, default=None, help="tuning aid: hip_ops.tune_wgrad flags (8 = generic 3x3 weight-gradient kernel)")
     ap.add_argument("--force-dp", action="store_true",
                     help="rehearsal on ONE GPU: run the N > 1 code path (SyncBatchNorm containers, bucket reducer, RCCL collectives captured "
@@ -180,6 +181,8 @@ def run_inference(args):
     hip_ops.set_mma_mode(args.mma)
     if args.wgrad_flags is not None:
         hip_ops.tune_wgrad(args.wgrad_flags)
+    if args.tune_k_tile is not None:
+        hip_ops.tune_k_tile(args.tune_k_tile)
     torch.cuda.set_device(0)
     torch.manual_seed(0)
     clips, T, H, W = 32, args.frames, args.height, args.width
@@ -255,6 +258,8 @@ def main():
     hip_ops.set_mma_mode(args.mma)
     if args.wgrad_flags is not None:
         hip_ops.tune_wgrad(args.wgrad_flags)
+    if args.tune_k_tile is not None:
+        hip_ops.tune_k_tile(args.tune_k_tile)
     torch.manual_seed(3407)
     cfg = make_cfg(img_h=args.height, img_w=args.width, arch=args.arch)
     model = RouterOL(cfg, Criterion4OL(cfg)).to(dev).train()

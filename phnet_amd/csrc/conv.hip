@@ -494,6 +494,228 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(
                                                                nullptr, stats);
 }
 
+// ---- 3x3 / stride 1 / pad 1 forward and data gradient: the three taps of a filter row from ONE staged pixel block ----------
+// In the generic tile program every K step gathers its own A block: the steps of the taps (dy,-1), (dy,0), (dy,+1) fetch, split
+// and stage the SAME pixels shifted by one.  Here a "unit" = (filter row dy, 16-channel chunk) stages the 66 pixels m0-1 ..
+// m0+64 of the shifted image row ONCE (bf16 planes, K-contiguous) and runs three K steps on it: step dx reads its A fragments
+// dx rows further down the image and only the 64x16 weight tile is staged per step.  A-side loads, split arithmetic and LDS
+// fills fall 2.9x (a third of the loop's operand traffic and vector instructions; the what-if builds of DESIGN.md 7 price
+// them at ~20 of a layer's 54 us).  Rows whose tap leaves the image row (x = 0 for dx = -1, x = W-1 for dx = +1) are zeroed in
+// the fragment (a per-lane select, the flags are fixed over the K loop); block rows whose image row y + dy is outside the frame -
+// the block may span image rows and frames - are staged as zeros.  64x64 tile, 4 waves, bf16x3 arithmetic, buffer loads,
+// prefetch ring of one unit (three weight tiles + the next A block); epilogue (bias / addend / ReLU / BatchNorm statistics /
+// split-K partials) as in igemm_tile.  DGRAD: the same gather on dY with the flipped, transposed weight as B (K-strided planes).
+constexpr int T3_AROWS = 66;
+int g_taps3 = 1;                                             // tuning aid: phnet_tune_force_k_tile(-5 / -6) switches this kernel off / on
+template <bool DGRAD>
+__global__ __launch_bounds__(THREADS) void conv3x3s1_kernel(
+    const float* __restrict__ X, const float* __restrict__ Wt, const float* __restrict__ bias,
+    const float* __restrict__ addend, float* __restrict__ out, ConvShape g, int relu, float* __restrict__ stats)
+{
+    constexpr int APITCH = KContigPlanes<64, 16>::PITCH;     // 48 bytes: 16 bf16 + pad
+    constexpr int APLANE = T3_AROWS * APITCH, AIMG = 3 * APLANE;
+    typedef KContigPlanes<64, 16> BP3C;
+    typedef KStridedPlanes<64, 16> BP3S;
+    constexpr int BIMG = DGRAD ? BP3S::BYTES : BP3C::BYTES;
+    constexpr int BPLANE = DGRAD ? BP3S::PLANE : BP3C::PLANE;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    unsigned char* A3 = reinterpret_cast<unsigned char*>(lds);       // [2][3 planes][66 rows][48]
+    unsigned char* B3 = A3 + 2 * AIMG;                               // [2][3 planes]...
+    unsigned char* dump = B3 + 2 * BIMG;                             // 3 x 512 bytes: where lanes without a second A row write
+
+    const int W = g.Wi, H = g.Hi, Ca = g.Ci;                 // A-side image and channel count
+    const int M = g.N * H * W, K = 9 * Ca;
+    const int CC = Ca >> 4;                                  // 16-channel chunks
+    const int tiles_n = (g.Co + 63) >> 6;
+    const unsigned tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (int)(tile / tiles_n) * 64, n0 = (int)(tile % tiles_n) * 64;
+    const int u_begin = blockIdx.z * g.k_per_split, u_end = min(3 * CC, u_begin + g.k_per_split);      // units of this split
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+
+    // ---- A staging: 66 rows x 4 chunks = 264 float4, thread tid takes chunk idx = tid and (tid < 8) idx = 256 + tid ----
+    constexpr unsigned OOB = 0x80000000u;
+    __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)min((long)M * Ca * 4, (long)0x7fffffff), 0x00020000);
+    __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Wt, 0, (int)min((long)g.Co * K * 4, (long)0x7fffffff), 0x00020000);
+    int a_off[2], a_ok[2], a_lds[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = tid + 256 * i, row = idx >> 2, chunk = idx & 3;
+        const bool rowok = idx < 4 * T3_AROWS;
+        const int t = m0 - 1 + row;                          // aligned pixel of the row
+        const bool tok = rowok && (unsigned)t < (unsigned)M;
+        const int tt = tok ? t : 0;
+        const int y = (tt / W) % H;
+        a_ok[i] = (tok && y >= 1 ? 1 : 0) | (tok ? 2 : 0) | (tok && y + 1 < H ? 4 : 0);          // bit dyi: image row y + dyi - 1 exists
+        a_off[i] = (t * Ca + chunk * 4) * 4;
+        a_lds[i] = rowok ? row * APITCH + chunk * 8 : -1;
+    }
+    // ---- B staging (one float4 per thread and step), as in igemm_tile ----
+    const int a_row = tid >> 2, a_chunk = tid & 3;           // forward: weight row n0 + a_row, k chunk a_chunk
+    const int b_kk = tid >> 4, b_ch = tid & 15;              // dgrad: k row b_kk, columns n0 + 4 b_ch ..
+    int b_off, b_lds;
+    if (!DGRAD) {
+        const int n = n0 + a_row;
+        b_off = n < g.Co ? (n * K + a_chunk * 4) * 4 : (int)OOB;
+        b_lds = a_row * BP3C::PITCH + a_chunk * 8;
+    } else {
+        const int n = n0 + b_ch * 4;
+        b_off = n < g.Co ? (b_kk * 9 * g.Co + n) * 4 : (int)OOB;
+        b_lds = b_kk * BP3S::PITCH + b_ch * 8;
+    }
+    // running unit decomposition of the LOADS (they run ahead of the multiplies): unit -> (dyi, cc)
+    int la_dy = u_begin / CC, la_cc = u_begin - la_dy * CC, la_u = u_begin;           // next A block to load
+    int lb_dy = la_dy, lb_cc = la_cc, lb_u = u_begin, lb_dx = 0;                    // next weight tile to load
+    // (the 8 chunks past the first 256 belong to wave 0: the other waves skip them under a wave-uniform branch - done branch-free
+    // with a dump slot, every thread paid a second split per unit and the kernel gained nothing over the generic one)
+    const bool wave0 = __builtin_amdgcn_readfirstlane(wave) == 0;
+    auto load_a = [&](f32x4 (&reg)[2]) {
+        const bool uok = la_u < u_end;
+        const int s_a = ((la_dy - 1) * W * Ca + la_cc * 16) * 4;
+        {
+            const bool ok = uok && ((a_ok[0] >> la_dy) & 1);
+            reg[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, ok ? a_off[0] + s_a : (int)OOB, 0, 0));
+        }
+        if (wave0) {
+            const bool ok = uok && ((a_ok[1] >> la_dy) & 1);
+            reg[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, ok ? a_off[1] + s_a : (int)OOB, 0, 0));
+        }
+        ++la_u; ++la_cc;
+        const int wrap = la_cc == CC;
+        la_cc = wrap ? 0 : la_cc;
+        la_dy += wrap;
+    };
+    auto load_b = [&](f32x4& reg) {
+        const bool uok = lb_u < u_end;
+        const int s_b = !DGRAD ? ((lb_dy * 3 + lb_dx) * Ca + lb_cc * 16) * 4
+                               : ((lb_cc * 16 * 3 + (2 - lb_dy)) * 3 + (2 - lb_dx)) * g.Co * 4;
+        reg = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, uok ? b_off + s_b : (int)OOB, 0, 0));
+        ++lb_dx;
+        const int w3 = lb_dx == 3;
+        lb_dx = w3 ? 0 : lb_dx;
+        lb_u += w3; lb_cc += w3;
+        const int wrap = lb_cc == CC;
+        lb_cc = wrap ? 0 : lb_cc;
+        lb_dy += wrap;
+    };
+    auto store_a = [&](int aoff, const f32x4 (&reg)[2]) {
+        store_split3<APLANE>(A3 + aoff, a_lds[0], reg[0]);
+        if (wave0) {
+            // second chunk: the 8 lanes that have one write it into the image, the others (an out-of-range load: zeros) into the dump
+            unsigned h0, m0_, l0, h1, m1, l1;
+            split3_pair(reg[1].x, reg[1].y, h0, m0_, l0);
+            split3_pair(reg[1].z, reg[1].w, h1, m1, l1);
+            const bool has = a_lds[1] >= 0;
+            unsigned char* q = has ? A3 + aoff + a_lds[1] : dump + lane * 8;
+            const int ps = has ? APLANE : 512;
+            *reinterpret_cast<u32x2*>(q) = (u32x2){h0, h1};
+            *reinterpret_cast<u32x2*>(q + ps) = (u32x2){m0_, m1};
+            *reinterpret_cast<u32x2*>(q + 2 * ps) = (u32x2){l0, l1};
+        }
+    };
+    auto store_b = [&](int boff, const f32x4& reg) { store_split3<BPLANE>(B3 + boff, b_lds, reg); };
+
+    // accumulators start from bias (+ addend) when this launch is the final pass (igemm_tile)
+    const bool final_pass = g.splits == 1;
+    f32x16 acc[1][1];
+    {
+        const int n = n0 + wn + frag_col(lane);
+        const bool nok = n < g.Co;
+        const float bv = (final_pass && bias && nok) ? bias[n] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int m = m0 + wm + frag_row(lane, e);
+            const bool ok = final_pass && addend && nok && m < M;
+            acc[0][0][e] = bv + (ok ? addend[(size_t)(ok ? m : 0) * g.Co + (ok ? n : 0)] : 0.f);
+        }
+    }
+    // per-lane border flags of this lane's A row (pixel m0 + wm + (lane & 31)): fixed over the K loop
+    const int pr = m0 + wm + (lane & 31);
+    const int px = (pr < M ? pr : 0) % W;
+    const bool edge_l = px == 0, edge_r = px == W - 1;
+
+    if (u_begin < u_end) {
+        f32x4 a_reg[2], b_set[3];
+        load_a(a_reg);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) load_b(b_set[d]);
+        store_a(0, a_reg);
+        load_a(a_reg);
+        store_b(0, b_set[0]);
+        load_b(b_set[0]);
+        __syncthreads();
+        int aoff = 0, boff = 0;                              // byte offsets of the A image / weight tile being multiplied
+        const int r = lane & 31, hb = (lane >> 5) * 16;
+        auto step = [&](auto DX) {
+            constexpr int dxi = decltype(DX)::value;
+            {
+                Frag3 a[1], b[1];
+                {
+                    const unsigned char* p = A3 + aoff + (wm + r + dxi) * APITCH + hb;
+                    a[0].hi = *reinterpret_cast<const bf16x8*>(p);
+                    a[0].mid = *reinterpret_cast<const bf16x8*>(p + APLANE);
+                    a[0].lo = *reinterpret_cast<const bf16x8*>(p + 2 * APLANE);
+                }
+                if (!DGRAD) read_kcontig3<1, BP3C::PITCH, BP3C::PLANE>(B3 + boff + wn * BP3C::PITCH, lane, 0, b);
+                else read_kstrided3<1, BP3S::PITCH, BP3S::PLANE>(B3 + boff + wn * 2, lane, 0, b);
+                if (dxi != 1) {                               // the tap leaves the image row on this lane's pixel: a zero row
+                    const bool z = dxi == 0 ? edge_l : edge_r;
+                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                    const u32x4 keep = z ? (u32x4){0u, 0u, 0u, 0u} : (u32x4){~0u, ~0u, ~0u, ~0u};
+                    a[0].hi = __builtin_bit_cast(bf16x8, __builtin_bit_cast(u32x4, a[0].hi) & keep);
+                    a[0].mid = __builtin_bit_cast(bf16x8, __builtin_bit_cast(u32x4, a[0].mid) & keep);
+                    a[0].lo = __builtin_bit_cast(bf16x8, __builtin_bit_cast(u32x4, a[0].lo) & keep);
+                }
+                mma3_step<1, 1>(a, b, acc);
+                // the next weight tile moves from its ring slot into the other LDS buffer; the slot takes the tile a unit ahead
+                store_b(boff ^ BIMG, b_set[(dxi + 1) % 3]);
+                load_b(b_set[(dxi + 1) % 3]);
+                if (dxi == 2) {                               // ... and, on a unit's last step, the next A block
+                    store_a(aoff ^ AIMG, a_reg);
+                    load_a(a_reg);
+                }
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {                 // an MFMA, then a few of the split / address instructions, ...
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, dxi == 2 ? 14 : 8, 0);
+                }
+                __syncthreads();
+                boff ^= BIMG;
+            }
+        };
+        for (int u = u_begin; u < u_end; ++u) {
+            step(std::integral_constant<int, 0>{});
+            step(std::integral_constant<int, 1>{});
+            step(std::integral_constant<int, 2>{});
+            aoff ^= AIMG;
+        }
+    }
+
+    // ---- per-channel statistics of the result for a following BatchNorm (igemm_tile) ----
+    if (stats != nullptr && final_pass) {
+        const int n = n0 + wn + frag_col(lane);
+        float sm = 0.f, sq = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { const float v = acc[0][0][e]; sm += v; sq += v * v; }
+        sm += __shfl_xor(sm, 32, 64);
+        sq += __shfl_xor(sq, 32, 64);
+        if (lane < 32 && n < g.Co) {
+            float* p = stats + (size_t)((m0 + wm) >> 5) * 2 * g.Co;
+            p[n] = sm;
+            p[g.Co + n] = sq;
+        }
+    }
+    float* dst = out + (size_t)blockIdx.z * M * g.Co;
+    const int n = n0 + wn + frag_col(lane);
+    if (n < g.Co) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int m = m0 + wm + frag_row(lane, e);
+            if (m < M) dst[(size_t)m * g.Co + n] = (final_pass && relu) ? fmaxf(acc[0][0][e], 0.f) : acc[0][0][e];
+        }
+    }
+}
+
 // out[i] = sum_z part[z][i] (+bias[i % ncols]) (relu)
 // Every operand of an output element is fetched before the first add (the first eight partial sums branch-free - a
 // split index past the end re-reads the last one - plus bias, addend and the old value): one memory latency per launch
@@ -1338,11 +1560,23 @@ int launch_conv(const float* X, const float* W, const float* bias, const float* 
     } while (0)
     // uniform-tap variant (the production tile only): the A-side channel count is a multiple of the K tile
     const bool uni = (g.Ci % bkt) == 0 && g_uniform_tap;
+    if (g_taps3 && uni && g.R == 3 && g.S == 3 && g.stride == 1 && g.pad == 1 && g.in_dil == 1 && g.Ho == g.Hi && g.Wo == g.Wi &&
+        t.bm == 64 && t.bn == 64 && bkt == 16 && g_mma_mode == 3 && g_buf_loads && g_pf == 4 && g.Wi >= 2 &&
+        M * (long)g.Ci * 4 < 0x7fffffffL && (long)g.Co * K * 4 < 0x7fffffffL) {
+        const int units = 3 * (g.Ci / 16);
+        g.k_per_split = (units + splits - 1) / splits;                   // in units for this kernel
+        constexpr size_t lds_ = 2 * 3 * T3_AROWS * KContigPlanes<64, 16>::PITCH +
+                                2 * (size_t)(DGRAD ? KStridedPlanes<64, 16>::BYTES : KContigPlanes<64, 16>::BYTES) + 3 * 512;
+        hipLaunchKernelGGL((conv3x3s1_kernel<DGRAD>), grid, dim3(THREADS), lds_, st,
+                           X, W, bias, addend, dst, g, relu, splits > 1 ? (float*)nullptr : stats);
+    } else
+    {
     if (t.bm == 128 && t.bn == 128) PHNET_LAUNCH_CONV(128, 128, false);
     else if (t.bm == 128 && t.bn == 64) PHNET_LAUNCH_CONV(128, 64, false);
     else if (t.bm == 64 && t.bn == 128) PHNET_LAUNCH_CONV(64, 128, false);
     else if (uni) PHNET_LAUNCH_CONV(64, 64, true);
     else PHNET_LAUNCH_CONV(64, 64, false);
+    }
 #undef PHNET_LAUNCH_CONV____
 #undef PHNET_LAUNCH_CONV___
 #undef PHNET_LAUNCH_CONV__
@@ -1411,6 +1645,7 @@ PHNET_API int phnet_tune_mma(int32_t mode)
 PHNET_API int phnet_tune_force_k_tile(int32_t kt)
 {
     if (kt == -1 || kt == -2) { g_uniform_tap = kt == -2; return PHNET_OK; }     // -1: uniform-tap variant off, -2: on again
+    if (kt == -5 || kt == -6) { g_taps3 = kt == -6; return PHNET_OK; }          // -5: three-taps 3x3 forward / dgrad kernel off, -6: on again
     if (kt == -32 || kt == -64) { g_deep_kt3 = -kt; return PHNET_OK; }
     if (kt == -101 || kt == -102 || kt == -104) { g_pf = -kt - 100; return PHNET_OK; }
     if (kt == -200 || kt == -201) { g_buf_loads = -kt - 200; return PHNET_OK; }

@@ -19,7 +19,10 @@ TIMER = None
 _MMA_MODE = 3        # arithmetic of the GEMM kernels (set_mma_mode; 3 = "bf16x3", the library default); here only used to NAME kernel symbols for bench.py
 
 
-def _gemm_symbol(m, co, k, ws_bytes, dgrad, ci_a, in_dil=1):
+_TAPS3 = True           # mirrors csrc/conv.hip g_taps3 (kernel names of the bench's per-kernel accounting only)
+
+
+def _gemm_symbol(m, co, k, ws_bytes, dgrad, ci_a, in_dil=1, taps3=False):
     import ctypes
     bm, bn, sp, kt = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
     check(lib().phnet_conv2d_plan(m, co, k, ws_bytes, ctypes.byref(bm), ctypes.byref(bn), ctypes.byref(sp), ctypes.byref(kt)),
@@ -27,6 +30,8 @@ def _gemm_symbol(m, co, k, ws_bytes, dgrad, ci_a, in_dil=1):
     uni = bm.value == 64 and bn.value == 64 and ci_a % kt.value == 0      # uniform-tap variant (csrc/conv.hip)
     pf = 4 if _MMA_MODE == 3 else 1                                       # register prefetch ring; buffer loads (launch_conv)
     buf = uni and _MMA_MODE == 3 and in_dil == 1
+    if taps3 and buf and kt.value == 16 and _TAPS3:                       # three-taps 3x3 / stride-1 kernel (launch_conv)
+        return f"conv3x3s1_kernel<{'true' if dgrad else 'false'}>", sp.value
     return (f"conv_igemm_kernel<{bm.value}, {bn.value}, {'true' if dgrad else 'false'}, {kt.value}, {'true' if uni else 'false'}, "
             f"{_MMA_MODE}, {pf}, {'true' if buf else 'false'}>", sp.value)
 
@@ -158,12 +163,12 @@ def conv2d_fwd(x, w, bias, stride: int, pad: int, relu: bool = False, out: Optio
         if addend is not None:
             _req(addend, name="addend")
             assert addend.shape == out.shape
-        _timed_launch(lambda: _gemm_symbol(m, co, k, need, False, ci), 2.0 * m * co * k,
+        _timed_launch(lambda: _gemm_symbol(m, co, k, need, False, ci, taps3=(r == 3 and s == 3 and stride == 1 and pad == 1)), 2.0 * m * co * k,
                       lambda: check(lib().phnet_conv2d_fwd_fused(_ptr(x), _ptr(w), _ptr(bias), _ptr(addend), _ptr(out), _ptr(part), n, hi, wi,
                                                                  ci, co, r, s, stride, pad, int(relu), _ptr(ws), need, _stream()),
                                     "phnet_conv2d_fwd_fused"), shape=("fwd", m, co, k, r))
         return (out, (part, nblk)) if stats else out
-    _timed_launch(lambda: _gemm_symbol(m, co, k, need, False, ci), 2.0 * m * co * k,
+    _timed_launch(lambda: _gemm_symbol(m, co, k, need, False, ci, taps3=(r == 3 and s == 3 and stride == 1 and pad == 1)), 2.0 * m * co * k,
                   lambda: check(lib().phnet_conv2d_fwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(out), n, hi, wi, ci, co, r, s, stride,
                                                        pad, int(relu), _ptr(ws), need, _stream()), "phnet_conv2d_fwd"),
                   shape=("fwd", m, co, k, r))
@@ -179,7 +184,7 @@ def conv2d_dgrad(dy, w, in_hw: Tuple[int, int], stride: int, pad: int, addend: O
     need = 8 * n * hi * wi * ci * 4 if n * hi * wi * ci < (1 << 23) else 0
     ws = workspace(need, dy.device) if need else None
     m, k = n * hi * wi, r * s * co
-    _timed_launch(lambda: _gemm_symbol(m, ci, k, need, True, co, stride), 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * co * r * s * ci,
+    _timed_launch(lambda: _gemm_symbol(m, ci, k, need, True, co, stride, taps3=(r == 3 and s == 3 and stride == 1 and pad == 1)), 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * co * r * s * ci,
                   lambda: check(lib().phnet_conv2d_dgrad(_ptr(dy), _ptr(w), _ptr(addend), _ptr(dx), n, hi, wi, ci, co, r, s, stride,
                                                          pad, _ptr(ws), need, _stream()), "phnet_conv2d_dgrad"),
                   shape=("dgrad", m, ci, k, r))
@@ -953,6 +958,14 @@ def lane_mask_stats(masks, pairs, width: int):
 def lane_mask_iou(segs, n_lanes: int, pairs, height: int, width: int, lane_width: int):
     """Areas of the drawn lanes and the pairwise intersections the IoU matrices need, two launches."""
     return lane_mask_stats(lane_raster(segs, n_lanes, height, width, lane_width), pairs, width)
+
+
+def tune_k_tile(code: int) -> None:
+    """Benchmark aid (process-global): phnet_tune_force_k_tile; -5 / -6 switch the three-taps 3x3 forward / dgrad kernel off / on."""
+    global _TAPS3
+    check(lib().phnet_tune_force_k_tile(code), "phnet_tune_force_k_tile")
+    if code in (-5, -6):
+        _TAPS3 = code == -6
 
 
 def tune_wgrad(flags: int = 1, target: int = 768) -> None:

@@ -295,6 +295,51 @@ def test_wgrad_three_taps_kernel_vs_fp64(ops, bf16x3, case):
             assert lib().phnet_tune_wgrad(1, -256) == 0
 
 
+@pytest.mark.parametrize("case", [(2, 16, 20, 64, 64), (3, 5, 17, 16, 36), (2, 7, 16, 48, 64), (1, 1, 70, 32, 128), (5, 20, 50, 256, 64),
+                                  (1, 10, 25, 512, 512), (4, 3, 2, 64, 64), (1, 80, 200, 64, 64)])
+def test_conv3x3_three_taps_forward_and_dgrad_vs_fp64(ops, bf16x3, case):
+    """conv3x3s1_kernel (3x3 / stride 1 / pad 1: a staged 66-pixel block serves the three taps of a filter row): blocks that span
+    image rows and frames, one-row and two-pixel-wide images, pixel counts that are no multiple of the tile, channel counts of 1-3
+    chunks and ragged output channels, split-K, bias / addend / ReLU epilogue and the BatchNorm statistics - against fp64 at the
+    generic kernel's tolerance and against the generic kernel (phnet_tune_force_k_tile(-5) switches this one off)."""
+    from phnet_amd._lib import lib
+    N, Hi, Wi, Ci, Co = case
+    torch.manual_seed(sum(case) + 17)
+    x = torch.randn(N, Ci, Hi, Wi, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn(Co, Ci, 3, 3, dtype=torch.float64) / (Ci * 9) ** 0.5)
+    b = torch.randn(Co, dtype=torch.float64)
+    ref = F.conv2d(x, w, b, stride=1, padding=1)
+    gy = torch.randn_like(ref)
+    ref.backward(gy)
+    xd, wd, gyd = nhwc(x.detach().float()), nhwc(w.float()), nhwc(gy.float())
+    add = torch.randn(N, Hi, Wi, Co, device="cuda")
+    def run():
+        y = ops.conv2d_fwd(xd, wd, dev(b.float()), 1, 1)
+        yr = ops.conv2d_fwd(xd, wd, dev(b.float()), 1, 1, relu=True, addend=add)
+        st = ops.conv2d_fwd(xd, wd, None, 1, 1, stats=True) if Co & (Co - 1) == 0 else None
+        dx = ops.conv2d_dgrad(gyd, wd, (Hi, Wi), 1, 1)
+        dxa = ops.conv2d_dgrad(gyd, wd, (Hi, Wi), 1, 1, addend=xd)
+        return y, yr, st, dx, dxa
+    y, yr, st, dx, dxa = run()
+    close(y, ref.detach().permute(0, 2, 3, 1), 2e-5)
+    close(yr, F.relu(ref.detach().permute(0, 2, 3, 1) + add.cpu().double()), 2e-5)
+    close(dx, x.grad.permute(0, 2, 3, 1), 2e-5)
+    close(dxa, x.grad.permute(0, 2, 3, 1) + x.detach().permute(0, 2, 3, 1), 2e-5)
+    if st is not None:
+        y0, (part, nblk) = st
+        raw = (ref.detach() - b.view(1, -1, 1, 1)).permute(0, 2, 3, 1).reshape(-1, Co)
+        sums = part.view(torch.float32)[:nblk * 2 * Co].view(nblk, 2, Co).double().sum(0).cpu()
+        assert float((sums[0] - raw.sum(0)).abs().max()) <= 1e-4 * float(raw.abs().sum(0).max())
+        assert float((sums[1] - (raw * raw).sum(0)).abs().max()) <= 1e-4 * float((raw * raw).sum(0).max())
+    assert lib().phnet_tune_force_k_tile(-5) == 0
+    try:
+        g = run()
+    finally:
+        assert lib().phnet_tune_force_k_tile(-6) == 0
+    for a_, b_ in ((y, g[0]), (yr, g[1]), (dx, g[3]), (dxa, g[4])):
+        assert float((a_ - b_).abs().max()) <= 4e-5 * float(b_.abs().max())
+
+
 def test_bf16x3_split_is_exact_on_adversarial_values(ops, bf16x3):
     """Operands chosen so that a two-term split would visibly lose bits: every mantissa bit set, magnitudes from 2^-100 to
     2^100 in one row, exact cancellation.  A 1x1 'convolution' with K = 64 against fp64."""

@@ -58,6 +58,9 @@ def main():
         pf = int(sys.argv[sys.argv.index("--pf") + 1])
         assert lib().phnet_tune_force_k_tile(-100 - pf) == 0
         print("register prefetch depth", pf)
+    if "--no-taps3" in sys.argv:
+        assert lib().phnet_tune_force_k_tile(-5) == 0
+        print("three-taps 3x3 forward / dgrad kernel off")
     only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None
     for name, N, Hi, Wi, Ci, Co, R, st, pad in (SHAPES[:4] if TRUNK_ONLY else SHAPES):
         if only and only not in name:
