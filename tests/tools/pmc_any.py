@@ -9,7 +9,7 @@ def short(name):
     return (m.group(1) if m else name)[:90]
 
 
-prefix = sys.argv[3] if len(sys.argv) > 3 else "conv_"
+prefix = sys.argv[3] if len(sys.argv) > 3 else "conv"
 acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
 for path in glob.glob(sys.argv[1], recursive=True):
     per_dispatch = collections.defaultdict(dict)

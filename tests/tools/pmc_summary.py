@@ -22,7 +22,7 @@ f = load(sys.argv[1], "FETCH_SIZE")
 w = load(sys.argv[2], "WRITE_SIZE")
 out = {}
 for k in sorted(f, key=lambda k: -f[k][1]):
-    if not (k.startswith("conv_") or k.startswith("gate_") or k.startswith("layernorm") or k.startswith("bn_") or k.startswith("roi_")
+    if not (k.startswith("conv") or k.startswith("gate_") or k.startswith("layernorm") or k.startswith("bn_") or k.startswith("roi_")
             or k.startswith("channel_") or k.startswith("linear_") or k.startswith("dyn_") or k.startswith("attn_") or k.startswith("lane_") or k.startswith("frame_loss")):
         continue
     n = f[k][0]
