@@ -87,9 +87,12 @@ int phnet_conv2d_plan(int64_t M, int32_t Co, int32_t K, uint64_t ws_bytes, int32
                       int32_t* k_tile);
 /* tuning aid for benchmarks only (process-global): force tile/split-K of the next fwd/dgrad calls; bm=0 -> heuristic. */
 int phnet_tune_force_conv_tile(int32_t bm, int32_t bn, int32_t splits);
-int phnet_tune_force_k_tile(int32_t k_tile);   /* 0 = heuristic, else 16 | 32 | 64; -1 / -2: uniform-tap kernel variant off / on */
-int phnet_tune_wgrad(int32_t allow_bm128, int32_t target_blocks);   /* wgrad tile / split-K policy; bit 1 of the first
-                                                                        argument disables the few-rows Linear kernel */
+int phnet_tune_force_k_tile(int32_t k_tile);   /* 0 = heuristic, else 16 | 32 | 64; -1 / -2: uniform-tap kernel variant off / on;
+                                                  -5 / -6: three-taps 3x3 stride-1 forward / dgrad kernel off / on */
+int phnet_tune_wgrad(int32_t allow_bm128, int32_t target_blocks);   /* wgrad tile / split-K policy; bits of the first argument:
+                                                                        1 = no few-rows Linear kernel, 3 = no three-taps 3x3 kernel,
+                                                                        4 = its 32-pixel steps; a NEGATIVE second argument sets the
+                                                                        three-taps kernel's workgroup target (default 256) */
 /* arithmetic of conv2d fwd / dgrad / wgrad (process-global): 0 = f32-input MFMA (default, what every published number
  * uses), 1 = split-bf16: operands split in registers into two bf16 terms, 3 bf16 MFMAs per product, f32 accumulation
  * (~2^-16 relative per product); 2 = exact three-term bf16 split, 6 bf16 MFMAs per product (dropped terms <= 2^-24:
