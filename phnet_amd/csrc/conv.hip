@@ -633,6 +633,7 @@ __global__ __launch_bounds__(THREADS) void conv3x3s1_kernel(
     const int pr = m0 + wm + (lane & 31);
     const int px = (pr < M ? pr : 0) % W;
     const bool edge_l = px == 0, edge_r = px == W - 1;
+    const bool any_l = __builtin_amdgcn_ballot_w64(edge_l) != 0, any_r = __builtin_amdgcn_ballot_w64(edge_r) != 0;
 
     if (u_begin < u_end) {
         f32x4 a_reg[2], b_set[3];
@@ -658,8 +659,8 @@ __global__ __launch_bounds__(THREADS) void conv3x3s1_kernel(
                 }
                 if (!DGRAD) read_kcontig3<1, BP3C::PITCH, BP3C::PLANE>(B3 + boff + wn * BP3C::PITCH, lane, 0, b);
                 else read_kstrided3<1, BP3S::PITCH, BP3S::PLANE>(B3 + boff + wn * 2, lane, 0, b);
-                if (dxi != 1) {                               // the tap leaves the image row on this lane's pixel: a zero row
-                    const bool z = dxi == 0 ? edge_l : edge_r;
+                if (dxi != 1 && (dxi == 0 ? any_l : any_r)) {  // the tap leaves the image row on this lane's pixel: a zero row
+                    const bool z = dxi == 0 ? edge_l : edge_r;    // (wave-uniform skip: most waves of a wide image hold no border pixel)
                     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
                     const u32x4 keep = z ? (u32x4){0u, 0u, 0u, 0u} : (u32x4){~0u, ~0u, ~0u, ~0u};
                     a[0].hi = __builtin_bit_cast(bf16x8, __builtin_bit_cast(u32x4, a[0].hi) & keep);
