@@ -22,6 +22,34 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+
+def spawn_ranks_if_asked(argv):
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment: this process becomes a LAUNCHER - it starts the N ranks
+    as children (`python -m torch.distributed.run --nproc-per-node N bench.py <same flags>`, the reference's own launch:
+    command.sh `torchrun --nproc_per_node=4 trainOL.py`), relays their output (rank 0 prints the JSON line) and exits with their
+    status.  Runs before torch is imported: the launcher never touches the GPU, so nothing is ever exec'ed or forked from a
+    process that has initialised HIP."""
+    ap = argparse.ArgumentParser(add_help=False)
+    ap.add_argument("--gpus", type=int, default=1)
+    n = ap.parse_known_args(argv)[0].gpus
+    if n <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *argv]
+    print(f"[bench] launcher: starting {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
+if __name__ == "__main__":
+    spawn_ranks_if_asked(sys.argv[1:])
+
 import torch
 import torch.distributed as dist
 
@@ -74,6 +102,12 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL over xGMI; gloo only for "
                                                       "functional rehearsals of the N>1 path on a single GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="plumbing check, no GPU needed: the ranks rendezvous over --backend, count themselves with one all-reduce, "
+                         "rank 0 prints {n_gpus, ...} and everybody exits")
+    ap.add_argument("--collectives", default="rccl-streams", choices=["rccl-streams", "torch"],
+                    help="N > 1, nccl backend: rccl-streams (default) = raw ncclAllReduce calls on our own streams, capturable "
+                         "(phnet_amd/rccl.py); torch = torch.distributed Work objects, eager step only")
     ap.add_argument("--tune-k-tile", type=int, default=None, help="tuning aid: phnet_tune_force_k_tile code (-5 = generic 3x3 forward / dgrad kernel)")
     ap.add_argument("--wgrad-flags", type=int, default=None, help="tuning aid: hip_ops.tune_wgrad flags (8 = generic 3x3 weight-gradient kernel)")
     ap.add_argument("--force-dp", action="store_true",
@@ -228,6 +262,23 @@ def run_inference(args):
     print(json.dumps(out), flush=True)
 
 
+def rendezvous_only(args, rank, world):
+    """The launch plumbing without a GPU: every rank joins the process group, one all-reduce counts them."""
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend=args.backend, init_method="env://")
+        one = torch.ones(1)
+        dist.all_reduce(one)
+        seen = int(one.item())
+    else:
+        seen = 1
+    if rank == 0:
+        print(json.dumps({"rendezvous_only": True, "n_gpus": seen, "world_size_env": world, "backend": args.backend if world > 1 else None}),
+              flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     if args.inference:
@@ -235,16 +286,28 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if args.gpus == 1:                           # launched under torchrun without --gpus: the environment decides
+            print(f"[bench] --gpus not given, WORLD_SIZE={world}: running {world} ranks", file=sys.stderr, flush=True)
+        else:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus N` (it launches "
+                             "the ranks itself) or under torch.distributed.run with --nproc-per-node equal to --gpus")
+    if args.rendezvous_only:
+        return rendezvous_only(args, rank, world)
     dp = world > 1 or args.force_dp                  # the data-parallel code path
     if dp:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        os.environ.setdefault("TORCH_NCCL_CUDA_EVENT_CACHE", "0")      # no event recycling between eager and captured collectives (graphed.py)
         if world == 1:
             os.environ["PHNET_FORCE_COLLECTIVES"] = "1"
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
             os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(0 if (args.share_gpu or world == 1) else local_rank)
         dist.init_process_group(backend=args.backend, init_method="env://")
+        if dist.get_world_size() != world:
+            raise SystemExit(f"bench.py: the process group has {dist.get_world_size()} ranks, the environment said {world}")
+        if args.backend == "nccl" and args.collectives == "rccl-streams":
+            from phnet_amd import rccl
+            rccl.install()                           # two dedicated communicators, before anything is captured (phnet_amd/rccl.py)
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -307,8 +370,8 @@ def main():
         return loss
 
     graphed = None
-    if use_graph and dp and args.backend != "nccl":
-        use_graph = False                            # only RCCL collectives can be captured; a gloo rehearsal runs eagerly
+    if use_graph and dp and (args.backend != "nccl" or args.collectives != "rccl-streams"):
+        use_graph = False                            # only raw RCCL calls on our streams can be captured (phnet_amd/rccl.py)
     if use_graph:
         try:
             graphed = GraphedTrainStep(model, opt, clips[0], lanes, loss_divisor=T * CB * world, warmup=2, arena=arena, reducer=reducer)
@@ -422,7 +485,7 @@ def main():
         if world == 1 and CB == 1 and args.batched_extra > 1 and use_graph:
             batched = batched_extra(args)
         out = {"metric": f"clips/s ({T}x3x{args.height}x{args.width}) fwd+bwd", "value": round(world * CB * args.steps / dt, 4), "unit": "clips/s",
-               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+               "n_gpus": dist.get_world_size() if dp else 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": DTYPE[args.mma], "data": "synthetic",
                "config": {"workload": f"{T}-frame clip 3x{args.height}x{args.width}, {args.arch} + router + lane head, fwd+bwd+AdamW, "

@@ -4,9 +4,10 @@ The per-clip step is ~20 000 small launches (15 serial stage iterations); replay
 host from the loop.  Works because the training path is shape-static and sync-free (device-side label assignment,
 fixed-capacity memory tokens).  With data parallelism the RCCL collectives - SyncBatchNorm exchanges (device-resident
 counts: nothing is read on the host), gradient buckets overlapped with the trunk's backward - are captured in the same
-graph.  (Measured on this stack, ROCm 7.0 / RCCL 2.26 / torch 2.10: an RCCL all-reduce captures and replays fine; issuing
-collectives EAGERLY between captured segments does not work - the process group's watchdog thread polls the events of
-those eager collectives while the next segment is being captured and dies with hipErrorCapturedEvent.)
+graph.  Those collectives are raw `ncclAllReduce` calls on our own streams (phnet_amd/rccl.py), never torch.distributed
+Work objects: a torch collective under capture pulls the process group's internal stream into the capture and the group's
+watchdog thread dies (hipErrorCapturedEvent) on its next poll of any eager Work it has not retired yet - rccl.py has the
+mechanism; phnet_amd.parallel refuses torch collectives under capture.
 
 Capture caveat (PyTorch, not ours): autograd graphs of earlier EAGER steps on the default stream must be dead before a
 step is captured - a loss / gradient tensor that is still referenced keeps AccumulateGrad nodes bound to the default
@@ -15,17 +16,7 @@ from typing import Callable, Optional
 
 import torch
 
-
-def _drain_collective_watchdog(seconds: float = 0.5):
-    """Before a capture that contains collectives: let the process group's watchdog thread retire the EAGER collectives issued so
-    far.  It scans its work list every ~100 ms and queries their events; seen once in ~10 runs on this stack (torch 2.10 / RCCL
-    2.26): a scan that overlaps the capture dies with hipErrorCapturedEvent and takes the process down.  With the device idle and
-    the list empty when the capture starts there is nothing for it to query (captured collectives are never put on that list)."""
-    import time
-    import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized():
-        torch.cuda.synchronize()
-        time.sleep(seconds)
+from .trunk import weights_changed
 
 
 def data_parallel_step(model, arena, reducer, optimizer, frames, lanes, loss_divisor: float, stage_done=None):
@@ -68,6 +59,11 @@ class GraphedTrainStep:
         self.model, self.optimizer, self.arena, self.between, self.reducer = model, optimizer, arena, between, reducer
         self.frames, self.lanes = frames.clone(), lanes.clone()
         self.div = float(loss_divisor if loss_divisor is not None else frames.shape[0])
+        if reducer is not None:
+            import torch.distributed as dist
+            from . import parallel, rccl
+            if parallel.active() and dist.get_backend() == "nccl" and rccl.installed() is None:
+                rccl.install()                              # collective (every rank builds its step at the same point); eager
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -75,7 +71,6 @@ class GraphedTrainStep:
                 self._step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        _drain_collective_watchdog()
         self.graph = torch.cuda.CUDAGraph()
         self.graph_opt = None
         if arena is None:
@@ -84,8 +79,8 @@ class GraphedTrainStep:
             if arena is None or not hasattr(arena, "bucket_of_part"):
                 raise ValueError("GraphedTrainStep(reducer=...) needs the arena of FlatAdamW.for_model(backward_order=True)")
             # ONE graph for the whole data-parallel step, the RCCL collectives captured inside it (the asynchronous bucket
-            # all-reduces become parallel branches of the graph next to the trunk's backward).  thread_local: the watchdog
-            # thread of torch.distributed polls events while we capture.
+            # all-reduces become parallel branches of the graph next to the trunk's backward).  thread_local: other threads
+            # of the process (torch.distributed's watchdogs polling their own, never-capturing streams) may call HIP meanwhile.
             with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 self.loss = self._step()
         elif between is None:
@@ -126,6 +121,7 @@ class GraphedTrainStep:
             self.lanes.copy_(lanes, non_blocking=True)
         if hasattr(self.optimizer, "sync_lr"):
             self.optimizer.sync_lr()                    # LR schedule -> the device scalar the captured AdamW launch reads
+        weights_changed()                               # the replay updates weights / running statistics behind torch's version counters
         self.graph.replay()
         if self.graph_opt is not None:
             self.between()

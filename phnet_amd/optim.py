@@ -9,12 +9,21 @@ import torch
 
 from . import hip_ops as K
 from .arena import GradArena, _view_like
+from .trunk import weights_changed
 
 
-def split_decay(params: Iterable[torch.nn.Parameter]) -> Tuple[list, list]:
-    """(decayed, not decayed): 1-D parameters - biases, normalisation affine - carry no weight decay."""
-    params = [p for p in params if p.requires_grad]
-    return [p for p in params if p.dim() > 1], [p for p in params if p.dim() <= 1]
+def no_decay(name: str, p: torch.Tensor) -> bool:
+    """The reference's predicate (libs/utils/optimizer.py:47 set_weight_decay): no weight decay on 1-D parameters and on anything
+    NAMED `*.bias` - that includes the two-dimensional LayerNorm([C,P]) biases of the routing gate (`detNet.router.pre_norm.*.bias`,
+    `DWNets.*.bias`, shape (64,36)), which a `dim() > 1` test would decay."""
+    return p.dim() <= 1 or name.endswith(".bias")
+
+
+def split_decay(model: torch.nn.Module) -> Tuple[list, list]:
+    """(decayed, not decayed) in named_parameters() order = the two parameter groups build_optimizer hands to optim.AdamW
+    (libs/utils/optimizer.py:41-55)."""
+    named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+    return [p for n, p in named if not no_decay(n, p)], [p for n, p in named if no_decay(n, p)]
 
 
 def model_part(param_name: str) -> int:
@@ -39,7 +48,10 @@ class FlatAdamW(torch.optim.Optimizer):
     replay (GraphedTrainStep does that), so a schedule is followed without re-capturing."""
 
     def __init__(self, arena: GradArena, n_decay: int, lr: float = 1e-3, betas: Sequence[float] = (0.9, 0.999), eps: float = 1e-8,
-                 weight_decay: float = 1e-2):
+                 weight_decay: float = 1e-2, groups=None):
+        """groups: (decayed parameters, the rest), each in the order the CHECKPOINT numbers them (torch numbers parameters group by
+        group in the order of the lists given to the optimizer; the reference passes named_parameters() order).  The arena may lay
+        the same parameters out in any order as long as the decayed ones come first; default: the arena's order."""
         if arena.flat_params is None:
             raise ValueError("FlatAdamW needs GradArena(..., flatten_params=True)")
         self.arena, self.n_decay = arena, int(n_decay)
@@ -54,6 +66,10 @@ class FlatAdamW(torch.optim.Optimizer):
         for p in arena.params:                                                  # arena order: decayed parameters first
             (decayed if seen < self.n_decay else rest).append(p)
             seen += p.numel()
+        if groups is not None:
+            if {id(p) for p in groups[0]} != {id(p) for p in decayed} or {id(p) for p in groups[1]} != {id(p) for p in rest}:
+                raise ValueError("FlatAdamW: `groups` must hold exactly the arena's decayed / undecayed parameters")
+            decayed, rest = list(groups[0]), list(groups[1])
         groups = [{"params": decayed, "weight_decay": self.weight_decay}]
         if rest:
             groups.append({"params": rest, "weight_decay": 0.0})
@@ -67,15 +83,15 @@ class FlatAdamW(torch.optim.Optimizer):
         `arena.bucket_bounds` / `arena.bucket_of_part` describe 4 contiguous buckets for parallel.BucketReducer: bucket i can
         be all-reduced as soon as the part named in bucket_of_part has reported `stage_done` (the 1-D parameters - biases,
         normalisation affine: 0.3 % of the elements - travel with the last bucket)."""
+        model_order = split_decay(model)                      # what the checkpoint's numbering follows
         if not backward_order:
-            decay, no_decay = split_decay(model.parameters())
-            arena = GradArena(decay + no_decay, flatten_params=True)
-            return cls(arena, sum(p.numel() for p in decay), **kw), arena
+            arena = GradArena(model_order[0] + model_order[1], flatten_params=True)
+            return cls(arena, sum(p.numel() for p in model_order[0]), **kw), arena
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
         part = {id(p): model_part(n) for n, p in named}
-        decay = sorted([p for _, p in named if p.dim() > 1], key=lambda p: part[id(p)])          # stable: keeps module order inside a part
-        no_decay = sorted([p for _, p in named if p.dim() <= 1], key=lambda p: part[id(p)])
-        arena = GradArena(decay + no_decay, flatten_params=True)
+        decay = sorted(model_order[0], key=lambda p: part[id(p)])          # stable: keeps module order inside a part
+        rest = sorted(model_order[1], key=lambda p: part[id(p)])
+        arena = GradArena(decay + rest, flatten_params=True)
         n_decay = sum(p.numel() for p in decay)
         ends, off = {}, 0
         for p in decay:
@@ -90,7 +106,7 @@ class FlatAdamW(torch.optim.Optimizer):
         b3 = end_of(3) or b2                                   # layer3
         arena.bucket_bounds = [0, b1, b2, b3, arena.flat.numel()]
         arena.bucket_of_part = {"head": 0, "layer4": 1, "layer3": 2, "stem": 3}
-        return cls(arena, n_decay, **kw), arena
+        return cls(arena, n_decay, groups=model_order, **kw), arena
 
     def sync_lr(self):
         """Copies param_groups[0]['lr'] (what LR schedulers write) into the device scalar the kernel reads.  Not capturable:
@@ -120,6 +136,7 @@ class FlatAdamW(torch.optim.Optimizer):
         if not torch.cuda.is_current_stream_capturing():
             self.sync_lr()
         self.step_count.add_(1)
+        weights_changed()                                       # raw-pointer update: invalidates folded eval weights (trunk._folded)
         K.adamw_step(self.arena.flat_params, self.arena.flat, self.exp_avg, self.exp_avg_sq, self.n_decay, self.step_count,
                      lr, betas[0], betas[1], eps, wd, lr_dev=self.lr_dev)
 
@@ -130,9 +147,10 @@ class FlatAdamW(torch.optim.Optimizer):
     # ---- checkpoints: torch.optim.AdamW's own layout, so the reference's resume path works both ways
     # (trainOL.py:128 `optimizer.load_state_dict(checkpoint['optimizer'])`, :182 `'optimizer': optimizer.state_dict()`) ----
     def _param_slices(self):
-        """[(index in torch's numbering, offset, numel, parameter)]: torch numbers parameters group by group, which is the
-        arena order (decayed first)."""
-        return [(i, *self.arena.offsets[id(p)], p) for i, p in enumerate(self.arena.params)]
+        """[(index in torch's numbering, offset, numel, parameter)]: torch numbers parameters group by group in the order of the
+        groups' lists (for_model: named_parameters() order, as the reference's build_optimizer); where a parameter lives in the
+        arena is looked up by identity, not by position."""
+        return [(i, *self.arena.offsets[id(p)], p) for i, p in enumerate(q for g in self.param_groups for q in g["params"])]
 
     def state_dict(self):
         step = self.step_count.detach().to(torch.float32).reshape(()).cpu()

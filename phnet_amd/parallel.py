@@ -20,7 +20,6 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("TORCH_NCCL_CUDA_EVENT_CACHE", "0")      # no event recycling between eager and captured collectives (graphed.py)
         dist.init_process_group(backend=backend or ("nccl" if torch.cuda.is_available() else "gloo"), init_method="env://")
     return rank, world, local_rank
 
@@ -76,11 +75,34 @@ def merge_batch_statistics(mean: torch.Tensor, var_biased: torch.Tensor, count: 
     return g_mean.float(), g_var.float(), int(round(float(total)))
 
 
+def _direct(t: torch.Tensor, group=None):
+    """The RcclStreams transport (phnet_amd/rccl.py) when it is installed and applies: collectives of the data path then go
+    straight into RCCL on our streams and no torch Work object exists (required under hipGraph capture: rccl.py says why)."""
+    if group is not None or not t.is_cuda:
+        return None
+    from . import rccl
+    return rccl.installed()
+
+
 def allreduce_sum_(t: torch.Tensor, group=None) -> torch.Tensor:
     """In-place SUM over the ranks (blocking for the STREAM, not the host)."""
     if active(group):
-        run_collective(lambda: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group))
+        tr = _direct(t, group)
+        if tr is not None:
+            run_collective(lambda: tr.all_reduce_(t))
+        else:
+            _no_torch_collective_under_capture(t)
+            run_collective(lambda: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group))
     return t
+
+
+def _no_torch_collective_under_capture(t: torch.Tensor):
+    """A torch.distributed collective under capture pulls the process group's internal stream into the capture; the group's
+    watchdog thread then dies on its next poll of any not-yet-retired eager Work (hipErrorCapturedEvent, rccl.py).  Refused
+    loudly instead of racing: install phnet_amd.rccl first."""
+    if t.is_cuda and torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("torch.distributed collective under hipGraph capture: call phnet_amd.rccl.install() before capturing "
+                           "a data-parallel step (phnet_amd/rccl.py explains the watchdog abort this prevents)")
 
 
 def average_gradients_(params, bucket_bytes: int = 96 << 20, group=None) -> int:
@@ -143,6 +165,7 @@ class BucketReducer:
         self.flat, self.bounds, self.group = flat, list(bounds), group
         self.work = []
         self.issued = []
+        self.direct = None
 
     @property
     def n_buckets(self) -> int:
@@ -154,7 +177,14 @@ class BucketReducer:
         if hi <= lo or not active(self.group):
             return
 
+        tr = _direct(self.flat, self.group)
+        if tr is not None:
+            self.direct = tr
+            run_collective(lambda: tr.all_reduce_async_(self.flat[lo:hi]))
+            return
+
         def go():
+            _no_torch_collective_under_capture(self.flat)
             self.work.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         run_collective(go)
 
@@ -171,4 +201,7 @@ class BucketReducer:
             for w in self.work:
                 w.wait()
             self.work = []
+            if self.direct is not None:
+                self.direct.join()
+                self.direct = None
         run_collective(wait)

@@ -90,21 +90,29 @@ def _conv_bn(tape: list, x, conv: nn.Conv2d, bn, training: bool, relu: bool, res
     return rec.y
 
 
-_FOLD_CACHE = {}
+# Bumped by everything that changes weights or running statistics BEHIND torch's version counters: the HIP kernels write
+# through raw pointers (phnet_adamw_step, the BatchNorm running statistics of a training forward) and a hipGraph replay bumps
+# nothing.  Part of the fold cache's key: an eval pass after training steps must not see the weights folded before them.
+_WEIGHT_EPOCH = [0]
+
+
+def weights_changed():
+    _WEIGHT_EPOCH[0] += 1
 
 
 def _folded(conv: nn.Conv2d, bn, w_ohwi: torch.Tensor):
-    """(w * gamma / sqrt(var + eps) per output channel, beta - mean * gamma / sqrt(var + eps)) for an eval-mode conv -> BN pair."""
-    ver = (conv.weight._version, bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version,
-           conv.weight.data_ptr(), bn.running_mean.data_ptr(), w_ohwi.shape)
-    hit = _FOLD_CACHE.get(id(bn))
+    """(w * gamma / sqrt(var + eps) per output channel, beta - mean * gamma / sqrt(var + eps)) for an eval-mode conv -> BN pair.
+    Cached ON the BatchNorm module (dies with the model), valid while no tensor version moved and no raw-pointer writer ran."""
+    ver = (_WEIGHT_EPOCH[0], conv.weight._version, bn.weight._version, bn.bias._version, bn.running_mean._version,
+           bn.running_var._version, conv.weight.data_ptr(), bn.running_mean.data_ptr(), w_ohwi.shape)
+    hit = bn.__dict__.get("_phnet_fold")
     if hit is not None and hit[0] == ver:
         return hit[1], hit[2]
     with torch.no_grad():
         scale = bn.weight.detach() * torch.rsqrt(bn.running_var + bn.eps)
         wf = (w_ohwi.reshape(w_ohwi.shape[0], -1) * scale[:, None]).reshape(w_ohwi.shape).contiguous()
         bf = (bn.bias.detach() - bn.running_mean * scale).contiguous()
-    _FOLD_CACHE[id(bn)] = (ver, wf, bf)
+    bn.__dict__["_phnet_fold"] = (ver, wf, bf)
     return wf, bf
 
 
@@ -117,6 +125,8 @@ def encoder_fwd_schedule(enc, training: bool, frames: torch.Tensor):
     """(P3, P4, P5) NHWC and, in training, the tape for `encoder_bwd_schedule`."""
     model, neck = enc.backbone.model, enc.neck
     tape = []
+    if training:
+        weights_changed()                                      # running statistics are about to move (raw-pointer writes)
     x = K.nchw3_to_nhwc4(frames.contiguous())
     w_stem = K.pad_channels(ohwi(model.conv1.weight).view(-1, 3), 4).view(model.conv1.out_channels, 7, 7, 4)
     y = _conv_bn(tape, x, model.conv1, model.bn1, training, relu=True, w_override=w_stem)

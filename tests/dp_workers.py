@@ -19,7 +19,7 @@ def free_port():
 
 def _worker(rank, world, port, backend, fn, ret, env):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
-                      HSA_ENABLE_IPC_MODE_LEGACY="0", TORCH_NCCL_CUDA_EVENT_CACHE="0", **env)
+                      HSA_ENABLE_IPC_MODE_LEGACY="0", **env)
     torch.set_num_threads(2)
     if backend != "gloo" or fn.__name__.startswith("gpu_"):
         torch.cuda.set_device(0)
@@ -161,6 +161,49 @@ def gpu_two_rank_step_vs_pair_fixture(rank, world):
             "bounds": list(arena.bucket_bounds)}
 
 
+def gpu_two_ranks_two_clips_each_vs_quad_fixture(rank, world):
+    """BASELINE configs[2] as ONE workload (8 clips over 4 ranks = 2 clips per GPU, trainOL.py:141-146,205-212), scaled to the
+    one-GPU box: 2 ranks x 2 clips per rank.  Inside a rank the two clips run batched ([B,T,3,H,W]: lane head batched across
+    the clips, local BatchNorm sums over B*T frames); across the ranks SyncBatchNorm merges the sums - statistics over all four
+    clips, as in the fixture (the reference's trunk run once over the four clips' frames)."""
+    import json
+    from phnet_amd import parallel
+    from phnet_amd.graphed import data_parallel_step
+    from phnet_amd.optim import FlatAdamW
+    from tests import synth
+    g, model = _tiny_model(sync_bn=True)
+    T, B = 2, 2
+    seeds = (3407, 3408, 3409, 3410)[rank * B:(rank + 1) * B]
+    frames = torch.stack([synth.make_clip(g, T, seed=s) for s in seeds]).cuda()
+    lanes = torch.stack([synth.make_targets(g, T)] * B).cuda()
+    rec = {"matched": [], "loss": []}
+    crit = model.criterion
+    crit_fwd = crit.forward
+
+    def hook(o, gt, diff=None):
+        m, l = crit_fwd(o, gt, diff)
+        rec["matched"].append([[i for i in x.cpu().tolist() if i >= 0] for x in m])
+        rec["loss"].append(float(l.detach()))
+        return m, l
+    crit.forward = hook
+    opt, arena = FlatAdamW.for_model(model, lr=0.0, weight_decay=0.0)
+    reducer = parallel.BucketReducer(arena.flat, arena.bucket_bounds)
+    n_coll = [0]
+    parallel._RUNNER = lambda fn: (n_coll.__setitem__(0, n_coll[0] + 1), fn())[1]
+    try:
+        loss = data_parallel_step(model, arena, reducer, opt, frames, lanes, 1.0)
+    finally:
+        parallel._RUNNER = None
+    torch.cuda.synchronize()
+    crit.forward = crit_fwd
+    names = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "grad_names_resnet18.json")))
+    params = dict(model.named_parameters())
+    return {"loss": float(loss), "frame_loss": rec["loss"], "matched": rec["matched"], "collectives": n_coll[0],
+            "grad_norm": [float(params[k].grad.double().norm()) for k in names],
+            "bn1_mean": model.backbone.backbone.model.bn1.running_mean.cpu().numpy(),
+            "bn1_var": model.backbone.backbone.model.bn1.running_var.cpu().numpy()}
+
+
 def gpu_whole_step_graph_with_rccl_inside(rank, world):
     """One-rank RCCL group, collectives forced on: the data-parallel step (staged trunk, SyncBatchNorm exchanges, bucket
     all-reduces, AdamW) eagerly, then captured as ONE hipGraph with the RCCL collectives inside and replayed twice."""
@@ -226,18 +269,40 @@ def gpu_ddp_syncbn_wrap(rank, world):
 
 
 def gpu_rccl_inside_capture(rank, world):
-    """Can an RCCL all-reduce be captured in a hipGraph and replayed on this stack?  (The data-parallel product path
-    relies on it: GraphedTrainStep(reducer=...) captures the whole data-parallel step with its collectives.)"""
+    """phnet_amd.rccl.RcclStreams: raw ncclAllReduce calls on our streams (compute stream + side stream with fork / join) captured
+    in a hipGraph and replayed, next to EAGER torch collectives on the default group before and after the capture (their Work
+    objects sit on the watchdog's list while we capture - harmless, because the default group's stream never captures); and
+    phnet_amd.parallel refuses a torch collective under capture instead of racing the watchdog."""
+    from phnet_amd import parallel, rccl
     t = torch.ones(1024, device="cuda")
-    dist.all_reduce(t)
-    torch.cuda.synchronize()
+    dist.all_reduce(t)                                            # eager torch collective: an un-retired Work when the capture starts
+    tr = rccl.install()
+    small = torch.ones(33, dtype=torch.float64, device="cuda")
+    big = torch.ones(1 << 20, device="cuda")
+    refused = False
     try:
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, capture_error_mode="thread_local"):
-            t.mul_(2.0)
-            dist.all_reduce(t)
+            small.mul_(2.0)
+            parallel.allreduce_sum_(small)                        # -> tr.all_reduce_ on the capturing stream
+            big.mul_(3.0)
+            red = parallel.BucketReducer(big, [0, 1 << 19, 1 << 20])
+            red.issue(0)                                          # -> side stream: a parallel branch of the graph
+            small.add_(1.0)
+            red.finish()
+            big.add_(1.0)
+            rccl.uninstall()
+            try:
+                parallel.allreduce_sum_(small)                    # torch collective under capture: must raise, not race
+            except RuntimeError as e:
+                refused = "under hipGraph capture" in str(e)
+            rccl._ACTIVE[0] = tr
+        dist.all_reduce(t)                                        # eager again, right after the capture
         g.replay(); g.replay()
         torch.cuda.synchronize()
-        return {"captured": True, "value": float(t[0])}
+        return {"captured": True, "refused": refused, "small": float(small[0]), "big": float(big[0]), "big_last": float(big[-1]),
+                "calls": tr.calls, "eager": float(t[0])}
     except Exception as e:                                       # noqa: BLE001
-        return {"captured": False, "error": f"{type(e).__name__}: {str(e)[:200]}"}
+        return {"captured": False, "error": f"{type(e).__name__}: {str(e)[:300]}"}
+    finally:
+        rccl.uninstall()

@@ -228,16 +228,19 @@ def run_eval(model, g, T, tag, out):
     out[f"{tag}_lane_npts"], out[f"{tag}_lane_pts"], out[f"{tag}_lane_meta"] = npts, pts, meta
 
 
+QUAD_SEEDS = (3407, 3408, 3409, 3410)     # rank r holds clips 2r, 2r+1
 PAIR_SEEDS = (3407, 3408)
 
 
-def run_pair(model, g, T, out):
+def run_pair(model, g, T, out, seeds=None, tag="pair"):
     """Two clips as two data-parallel ranks with SyncBatchNorm (trainOL.py:141: convert_sync_batchnorm + DDP), emulated in
     one CPU process with the reference's own modules only: the trunk runs ONCE over the frames of both clips (= batch
     statistics over both ranks, and their backward), then each clip goes through RouterOL.forward with a stub in place of
     the trunk that hands out the clip's slice of those feature maps; the SUM of the two clip losses is back-propagated
     (DDP would average: a factor 1/2 on every gradient)."""
-    clips = [synth.make_clip(g, T, seed=s) for s in PAIR_SEEDS]
+    seeds = PAIR_SEEDS if seeds is None else seeds
+    n_clips = len(seeds)
+    clips = [synth.make_clip(g, T, seed=s) for s in seeds]
     lanes = synth.make_targets(g, T)
     model.train()
     model.zero_grad()
@@ -268,21 +271,21 @@ def run_pair(model, g, T, out):
         losses.append(model({"frame": fr, "lanes": lanes}))
     model.backbone = enc
     crit.forward = crit_fwd
-    total = losses[0] + losses[1]
+    total = sum(losses[1:], losses[0])
     total.backward()
     names, norms, heads = grad_digest(model)
-    out["pair_loss"] = np.float64(total.item())
-    out["pair_clip_loss"] = np.array([float(l.item()) for l in losses])
-    out["pair_frame_loss"] = np.array(rec["frame_loss"]).reshape(2, T)
-    mm = np.full((2, T, 3, g.max_lanes), -1, dtype=np.int64)
+    out[f"{tag}_loss"] = np.float64(total.item())
+    out[f"{tag}_clip_loss"] = np.array([float(l.item()) for l in losses])
+    out[f"{tag}_frame_loss"] = np.array(rec["frame_loss"]).reshape(n_clips, T)
+    mm = np.full((n_clips, T, 3, g.max_lanes), -1, dtype=np.int64)
     for i, per in enumerate(rec["matched"]):
         for s_, idx in enumerate(per):
             mm[i // T, i % T, s_, :len(idx)] = idx
-    out["pair_matched"] = mm
-    out["pair_grad_norm"], out["pair_grad_head"] = norms, heads
+    out[f"{tag}_matched"] = mm
+    out[f"{tag}_grad_norm"], out[f"{tag}_grad_head"] = norms, heads
     bn = model.backbone.backbone.model.bn1
-    out["pair_bn1_running_mean"] = bn.running_mean.numpy().copy()
-    out["pair_bn1_running_var"] = bn.running_var.numpy().copy()
+    out[f"{tag}_bn1_running_mean"] = bn.running_mean.numpy().copy()
+    out[f"{tag}_bn1_running_var"] = bn.running_var.numpy().copy()
     return names
 
 
@@ -303,6 +306,17 @@ def main():
         assert names == json.load(open(os.path.join(HERE, "grad_names_resnet18.json")))
         np.savez_compressed(os.path.join(HERE, "tiny_pair_syncbn_r18_64x160.npz"), **out)
         print("tiny pair", out["pair_loss"], out["pair_clip_loss"].tolist(), out["pair_matched"][:, 0].tolist())
+        return
+    if "--only-quad" in sys.argv:
+        # ---- BASELINE.json configs[2] as ONE workload, scaled down: 2 ranks x 2 clips per rank = 4 clips whose BatchNorm
+        # statistics are joint (SyncBatchNorm across the ranks AND the batch dimension inside a rank), summed loss ----------
+        g = O.Geometry(img_h=64, img_w=160, arch="resnet18")
+        model, _ = build_reference(g)
+        out = {}
+        names = run_pair(model, g, 2, out, seeds=QUAD_SEEDS, tag="quad")
+        assert names == json.load(open(os.path.join(HERE, "grad_names_resnet18.json")))
+        np.savez_compressed(os.path.join(HERE, "tiny_quad_syncbn_r18_64x160.npz"), **out)
+        print("tiny quad", out["quad_loss"], out["quad_clip_loss"].tolist(), out["quad_matched"][:, 0].tolist())
         return
     if "--only-config4" in sys.argv:
         # ---- BASELINE.json configs[3] geometry: 10-frame clip 3x384x960 (its DLA-34 backbone does not exist in the reference

@@ -729,7 +729,7 @@ def test_flat_adamw_matches_torch_adamw(ops):
         net[0].weight.data = net[0].weight.data.contiguous(memory_format=torch.channels_last)
         return net
     ref, net = make(), make()
-    decay, no_decay = split_decay(ref.parameters())
+    decay, no_decay = split_decay(ref)
     kw = dict(lr=5e-3, betas=(0.9, 0.99), eps=1e-8)
     topt = torch.optim.AdamW([{"params": decay, "weight_decay": 0.05}, {"params": no_decay, "weight_decay": 0.0}], **kw)
     fopt, arena = FlatAdamW.for_model(net, weight_decay=0.05, **kw)
@@ -798,7 +798,7 @@ def test_flat_adamw_matches_torch_adamw(ops):
         fopt_b, arena_b = FlatAdamW.for_model(net_b, lr=1.0, betas=(0.5, 0.5), eps=1e-3, weight_decay=0.5)   # all overwritten by the load
         net_c = make()
         net_c.load_state_dict(ref.state_dict())
-        dc, ndc = split_decay(net_c.parameters())
+        dc, ndc = split_decay(net_c)
         topt_c = torch.optim.AdamW([{"params": dc, "weight_decay": 0.9}, {"params": ndc, "weight_decay": 0.0}], lr=1.0)
         try:
             fopt_b.load_state_dict(tsd)

@@ -625,6 +625,38 @@ def test_inference_batched_over_clips_equals_clip_by_clip():
     _close(rows_g, rows_b, 1e-5, "graph replay")
 
 
+def test_inference_batched_equals_clip_by_clip_at_the_config5_geometry():
+    """BASELINE.json configs[4] at its real geometry (ResNet-34, 5 frames of 3x320x800, the bench's model: class heads redrawn so
+    that about half of the anchors pass conf_threshold): B = 8 clips through one batched pass == the same clips one by one - kept
+    counts and kept anchor indices identical, kept rows to fp32 re-association; the B = 8 hipGraph replay reproduces it."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from phnet_amd.config import make_cfg
+    from phnet_amd.graphed import GraphedInference
+    from phnet_amd.libs.models.Router4OL import RouterOL
+    from phnet_amd.synthetic import make_clip, spread_scores_
+    torch.manual_seed(0)
+    T, B, H, W = 5, 8, 320, 800
+    model = RouterOL(make_cfg(img_h=H, img_w=W, arch="resnet34"), None).cuda().eval()
+    spread_scores_(model)
+    clips = torch.stack([make_clip(H, W, T, seed=100 + b) for b in range(B)]).cuda()
+    with torch.no_grad():
+        rows_b, nums_b, anch_b = model.infer_clips_device(clips)
+        singles = [model.infer_device(clips[b]) for b in range(B)]
+    assert int(nums_b.sum()) >= B * T                              # the decode is not empty: lanes are kept, memories carry positives
+    for b in range(B):
+        rows_s, nums_s, anch_s = singles[b]
+        assert torch.equal(nums_b[b], nums_s), b
+        for t in range(T):
+            k = int(nums_s[t])
+            assert torch.equal(anch_b[b, t, :k], anch_s[t, :k]), (b, t)
+            _close(rows_b[b, t, :k], rows_s[t, :k], 2e-4, f"kept rows clip {b} frame {t}")
+    graph = GraphedInference(model, clips)
+    rows_g, nums_g, anch_g = graph(clips)
+    assert torch.equal(nums_g, nums_b) and torch.equal(anch_g, anch_b)
+    _close(rows_g, rows_b, 1e-5, "graph replay")
+
+
 def test_training_batched_over_clips_equals_clip_by_clip():
     """RouterOL.forward on [B,T,3,H,W]: the head batched across B clips gives the sum of the per-clip losses and the same
     head gradients.  (The trunk runs with frozen BatchNorm statistics here: with batch statistics the B-clip step is the
@@ -951,3 +983,47 @@ def test_training_step_with_the_loss4ol_criterion_equals_oracle_on_the_same_head
             assert rec["matched"][t][s].tolist() == matched[s].tolist(), (t, s)
     assert abs(float(loss) - ref) <= 2e-5 * abs(ref), (float(loss), ref)
     assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in model.parameters())
+
+
+def test_eval_after_flat_adamw_steps_sees_the_updated_weights():
+    """Per-epoch validation in one process (trainOL.py: train(...) then validate(...)): the eval path folds BatchNorm into the
+    convolution weights and caches the fold; FlatAdamW and the training forward write weights / running statistics through raw
+    pointers that bump no torch version counter.  eval -> optimizer steps (eager and hipGraph replay) -> eval must equal a
+    fresh model holding the updated state."""
+    from phnet_amd.graphed import GraphedTrainStep
+    from phnet_amd.optim import FlatAdamW
+    g = O.Geometry(img_h=64, img_w=160, arch="resnet18")
+    model = _build(g)
+    T = 2
+    frames, lanes = synth.make_clip(g, T).cuda(), synth.make_targets(g, T).cuda()
+
+    def eval_maps(m):
+        m.eval()
+        with torch.no_grad():
+            return [t.clone() for t in m.backbone(frames)]
+    before = eval_maps(model)
+    opt, arena = FlatAdamW.for_model(model, lr=1e-2, weight_decay=0.0)
+    try:
+        model.train()
+        arena.zero()
+        (model({"frame": frames, "lanes": lanes}) / T).backward()
+        opt.step()
+        torch.cuda.synchronize()
+        after_eager = eval_maps(model)
+        fresh = _build(g)
+        fresh.load_state_dict(model.state_dict(), strict=True)
+        want = eval_maps(fresh)
+        assert any(float((a - b).abs().max()) > 1e-4 for a, b in zip(before, after_eager))        # the step did move the maps
+        for a, b in zip(after_eager, want):
+            assert torch.equal(a, b)
+        model.train()
+        step = GraphedTrainStep(model, opt, frames, lanes, loss_divisor=T, warmup=1, arena=arena)
+        step(frames)
+        torch.cuda.synchronize()
+        after_graph = eval_maps(model)
+        fresh.load_state_dict(model.state_dict(), strict=True)
+        for a, b in zip(after_graph, eval_maps(fresh)):
+            assert torch.equal(a, b)
+        assert any(float((a - b).abs().max()) > 1e-5 for a, b in zip(after_graph, after_eager))
+    finally:
+        arena.release()

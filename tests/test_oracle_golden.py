@@ -171,19 +171,21 @@ def test_config4_geometry_ten_frame_clip_train():
 
 @pytest.mark.skipif(os.environ.get("PHNET_SLOW_TESTS") != "1", reason="1.5 minutes of CPU: set PHNET_SLOW_TESTS=1 (passes; the GPU "
                     "suite holds the HIP path to the same fixture on every run)")
-def test_tiny_pair_of_clips_with_joint_batchnorm_statistics():
+@pytest.mark.parametrize("tag,fixture,T,seeds", [("pair", "tiny_pair_syncbn_r18_64x160.npz", 3, (3407, 3408)),
+                                                ("quad", "tiny_quad_syncbn_r18_64x160.npz", 2, (3407, 3408, 3409, 3410))])
+def test_tiny_pair_of_clips_with_joint_batchnorm_statistics(tag, fixture, T, seeds):
     """Two clips = two data-parallel ranks with SyncBatchNorm (make_goldens.py --only-pair: the reference's trunk run once over
-    the frames of both clips, its head and criterion per clip, summed loss)."""
+    the frames of both clips, its head and criterion per clip, summed loss); quad: four clips = 2 ranks x 2 clips per rank
+    (BASELINE.json configs[2] as one workload, make_goldens.py --only-quad)."""
     g = O.Geometry(img_h=64, img_w=160, arch="resnet18")
-    gold = _load("tiny_pair_syncbn_r18_64x160.npz")
+    gold = {k.replace(tag + "_", "pair_", 1): v for k, v in _load(fixture).items()}
     names = json.load(open(os.path.join(GOLD, "grad_names_resnet18.json")))
-    T = 3
     sd = synth.make_state(g)
     for k, v in sd.items():
         if v.is_floating_point() and "running" not in k and k.split(".")[-1] not in (
                 "prior_feat_ys", "prior_ys", "priors", "priors_on_featmap"):
             v.requires_grad_(True)
-    clips = [synth.make_clip(g, T, seed=s) for s in (3407, 3408)]
+    clips = [synth.make_clip(g, T, seed=s) for s in seeds]
     feats = O.fpn_neck(sd, O.resnet_trunk(sd, torch.cat(clips), g, True, True))
     total, cols = 0.0, []
     for b, fr in enumerate(clips):
@@ -193,7 +195,7 @@ def test_tiny_pair_of_clips_with_joint_batchnorm_statistics():
         cols.append(col)
     total.backward()
     assert abs(total.item() - gold["pair_loss"]) <= 5e-4 * abs(gold["pair_loss"])
-    for b in range(2):
+    for b in range(len(seeds)):
         np.testing.assert_allclose(cols[b]["frame_loss"], gold["pair_frame_loss"][b], rtol=1e-3)
         for t in range(T):
             for s_ in range(3):

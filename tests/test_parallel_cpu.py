@@ -113,7 +113,7 @@ def test_backward_ordered_arena_and_bucket_bounds():
     from phnet_amd.config import make_cfg
     from phnet_amd.libs.models.Router4OL import RouterOL
     from phnet_amd.libs.utils.loss4OLV3 import Criterion4OL
-    from phnet_amd.optim import FlatAdamW, model_part
+    from phnet_amd.optim import FlatAdamW, model_part, no_decay
     from phnet_amd.trunk import PARTS
     cfg = make_cfg(img_h=64, img_w=160, arch="resnet18")
     model = RouterOL(cfg, Criterion4OL(cfg))
@@ -121,7 +121,7 @@ def test_backward_ordered_arena_and_bucket_bounds():
     try:
         names = {id(p): n for n, p in model.named_parameters()}
         parts = [model_part(names[id(p)]) for p in arena.params]
-        dims = [p.dim() > 1 for p in arena.params]
+        dims = [not no_decay(names[id(p)], p) for p in arena.params]
         n_dec = sum(dims)
         assert all(dims[:n_dec]) and not any(dims[n_dec:])                                  # decayed first (FlatAdamW contract)
         assert parts[:n_dec] == sorted(parts[:n_dec]) and parts[n_dec:] == sorted(parts[n_dec:])
@@ -151,3 +151,84 @@ def test_run_collective_default_and_hook():
     finally:
         parallel._RUNNER = None
     assert calls == ["a"]
+
+
+def _reference_groups(model):
+    """libs/utils/optimizer.py:41-55 set_weight_decay, restated: named_parameters() order, no decay on 1-D or `*.bias`."""
+    has, no = [], []
+    for name, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        (no if (len(p.shape) == 1 or name.endswith(".bias")) else has).append(p)
+    return [{"params": has}, {"params": no, "weight_decay": 0.0}]
+
+
+def test_flat_adamw_checkpoints_in_the_reference_numbering_on_the_real_model():
+    """trainOL.py:128,182: optimizer.state_dict() / load_state_dict() of the reference's optim.AdamW, built by build_optimizer
+    with set_weight_decay's two groups in named_parameters() order.  FlatAdamW lays the same parameters out in BACKWARD order
+    (lane head first) - the checkpoint numbering must not follow the arena: group sizes, the (64,36) LayerNorm biases in the
+    undecayed group, moments landing on the right parameters in both directions.  (Host logic only: no kernel runs.)"""
+    from phnet_amd.config import make_cfg
+    from phnet_amd.libs.models.Router4OL import RouterOL
+    from phnet_amd.libs.utils.loss4OLV3 import Criterion4OL
+    from phnet_amd.optim import FlatAdamW
+    cfg = make_cfg(img_h=64, img_w=160, arch="resnet18")
+    torch.manual_seed(0)
+    ref = RouterOL(cfg, Criterion4OL(cfg))
+    ours = RouterOL(cfg, Criterion4OL(cfg))
+    ours.load_state_dict(ref.state_dict())
+    topt = torch.optim.AdamW(_reference_groups(ref), lr=5e-4, betas=(0.9, 0.999), weight_decay=5e-4)
+    for i, p in enumerate(ref.parameters()):                      # a different recognisable gradient for every parameter
+        p.grad = torch.full_like(p, 1e-3 * (i + 1))
+    topt.step()
+    tsd = topt.state_dict()
+    fopt, arena = FlatAdamW.for_model(ours, lr=1.0, weight_decay=0.5)
+    try:
+        assert [len(g["params"]) for g in fopt.param_groups] == [len(g["params"]) for g in topt.param_groups]
+        two_dim_bias = [n for n, p in ours.named_parameters() if p.dim() == 2 and n.endswith(".bias")]
+        assert len(two_dim_bias) == 27                               # detNet.router.*: LayerNorm([64,36]) biases
+        names = {id(p): n for n, p in ours.named_parameters()}
+        undecayed = {names[id(p)] for p in fopt.param_groups[1]["params"]}
+        assert set(two_dim_bias) <= undecayed
+        for p in fopt.param_groups[1]["params"]:
+            assert arena.offsets[id(p)][0] >= fopt.n_decay            # what the kernel decays = the first group, nothing else
+        fopt.load_state_dict(tsd)
+        assert fopt.param_groups[0]["lr"] == 5e-4 and fopt.param_groups[0]["weight_decay"] == 5e-4 and int(fopt.step_count) == 1
+        for i, p in enumerate(ours.parameters()):
+            off, n = arena.offsets[id(p)]
+            g = 1e-3 * (i + 1)
+            assert torch.allclose(fopt.exp_avg[off:off + n], torch.full((n,), 0.1 * g), rtol=1e-6), names[id(p)]
+            assert torch.allclose(fopt.exp_avg_sq[off:off + n], torch.full((n,), 1e-3 * g * g), rtol=1e-5), names[id(p)]
+        # and back: our checkpoint into a fresh reference-style optim.AdamW
+        fsd = fopt.state_dict()
+        assert [g["params"] for g in fsd["param_groups"]] == [g["params"] for g in tsd["param_groups"]]
+        topt2 = torch.optim.AdamW(_reference_groups(ref), lr=1.0)
+        topt2.load_state_dict(fsd)
+        for k, st in tsd["state"].items():
+            assert torch.equal(topt2.state_dict()["state"][k]["exp_avg"], st["exp_avg"])
+            assert torch.equal(topt2.state_dict()["state"][k]["exp_avg_sq"], st["exp_avg_sq"])
+    finally:
+        arena.release()
+
+
+def test_bench_gpus_n_launches_n_ranks():
+    """`python bench.py --gpus 2` (no torchrun environment) must run TWO ranks: the script turns into a launcher before torch is
+    imported, starts the ranks with torch.distributed.run (the reference's launch, command.sh: torchrun --nproc_per_node=4
+    trainOL.py) and relays rank 0's JSON line, whose n_gpus is what the process group counted.  --rendezvous-only stops after
+    the rendezvous (no GPU here); a --gpus / WORLD_SIZE mismatch is refused."""
+    import json
+    import subprocess
+    import sys
+    bench = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--backend", "gloo", "--rendezvous-only"], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout                                    # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["world_size_env"] == 2 and d["backend"] == "gloo", d
+    assert "launcher: starting 2 ranks" in r.stderr
+    bad = subprocess.run([sys.executable, bench, "--gpus", "2", "--rendezvous-only"], env=dict(env, WORLD_SIZE="3", RANK="0"),
+                         capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and "WORLD_SIZE=3" in (bad.stderr + bad.stdout)

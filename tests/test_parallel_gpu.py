@@ -46,6 +46,36 @@ def test_two_rank_syncbn_step_equals_reference_pair_fixture():
     assert res[0]["grad_norm"] == res[1]["grad_norm"]
 
 
+def test_configs2_two_ranks_times_two_clips_vs_reference_quad_fixture():
+    """BASELINE.json configs[2] as ONE workload - several clips per GPU AND several ranks, BatchNorm statistics joint over all
+    of them (trainOL.py:141-146 convert_sync_batchnorm + DDP; 8 clips over 4 ranks there, 2 ranks x 2 clips here: one card).
+    Against tests/golden/tiny_quad_syncbn_r18_64x160.npz (make_goldens.py --only-quad: the reference's trunk run once over the
+    four clips' frames, its head and criterion per clip): summed loss, per-frame losses, matched indices (exact), BatchNorm
+    running statistics, per-parameter norms of the SUM-reduced gradient - identical on both ranks."""
+    _need_gpu()
+    from tests import dp_workers as W
+    gold = dict(np.load(os.path.join(GOLD, "tiny_quad_syncbn_r18_64x160.npz")))
+    names = json.load(open(os.path.join(GOLD, "grad_names_resnet18.json")))
+    res = W.run(W.gpu_two_ranks_two_clips_each_vs_quad_fixture, world=2, backend="gloo")
+    T, B = 2, 2
+    total = sum(r["loss"] for r in res)
+    assert abs(total - gold["quad_loss"]) <= 1e-3 * abs(gold["quad_loss"]), (total, gold["quad_loss"])
+    for rank, r in enumerate(res):
+        assert r["collectives"] == 2 * 20 + 4 + 1
+        for t in range(T):                                    # the criterion runs clip by clip inside every frame index
+            for b in range(B):
+                i, clip = t * B + b, rank * B + b
+                assert abs(r["frame_loss"][i] - gold["quad_frame_loss"][clip, t]) <= 1e-3 * abs(gold["quad_frame_loss"][clip, t]), (clip, t)
+                for s in range(3):
+                    assert r["matched"][i][s] == [j for j in gold["quad_matched"][clip, t, s].tolist() if j >= 0], (clip, t, s)
+        np.testing.assert_allclose(r["bn1_mean"], gold["quad_bn1_running_mean"], atol=1e-4)
+        np.testing.assert_allclose(r["bn1_var"], gold["quad_bn1_running_var"], rtol=1e-4, atol=1e-4)
+        for i, k in enumerate(names):
+            ref, got = float(gold["quad_grad_norm"][i]), r["grad_norm"][i]
+            assert abs(got - ref) <= (5e-2 if k.startswith("detNet.router.") else 5e-3) * ref + 1e-5, (rank, k, got, ref)
+    assert res[0]["grad_norm"] == res[1]["grad_norm"]
+
+
 def test_data_parallel_step_as_one_hipgraph_with_rccl_collectives_inside():
     """The data-parallel step (staged trunk, SyncBatchNorm exchanges with device-resident counts, 4 bucket all-reduces, AdamW)
     captured as ONE hipGraph with the RCCL collectives inside (one-rank RCCL group, collectives forced on): the replay
@@ -75,8 +105,11 @@ def test_reference_style_syncbn_ddp_wrapping_of_the_hip_model():
 
 
 def test_rccl_collective_inside_a_hipgraph_capture():
-    """An RCCL all-reduce captured in a hipGraph and replayed twice (what GraphedTrainStep(reducer=...) relies on)."""
+    """Raw RCCL all-reduces on our own streams (phnet_amd/rccl.py: what GraphedTrainStep(reducer=...) relies on) captured in a
+    hipGraph and replayed twice, with eager torch collectives on the default group right before and after the capture; a torch
+    collective UNDER capture is refused (it is what made the process group's watchdog abort in round 2)."""
     _need_gpu()
     from tests import dp_workers as W
-    (r,) = W.run(W.gpu_rccl_inside_capture, world=1, backend="nccl")
-    assert r["captured"] and r["value"] == 4.0, r
+    (r,) = W.run(W.gpu_rccl_inside_capture, world=1, backend="nccl", env={"PHNET_FORCE_COLLECTIVES": "1"})
+    assert r["captured"] and r["refused"], r
+    assert r["small"] == 7.0 and r["big"] == 13.0 and r["big_last"] == 13.0 and r["calls"] == 3 and r["eager"] == 1.0, r
