@@ -80,6 +80,26 @@ int phnet_conv2d_fwd_fused(const float* x, const float* w, const float* bias, co
 int phnet_conv2d_dgrad(const float* dy, const float* w, const float* addend, float* dx,
                        int32_t N, int32_t Hi, int32_t Wi, int32_t Ci, int32_t Co, int32_t R, int32_t S,
                        int32_t stride, int32_t pad, void* workspace, uint64_t ws_bytes, void* stream);
+/* ---- 3x3 / stride 1 / pad 1 convolutions on PACKED weights (csrc/conv3p.hip): the trunk / FPN 3x3 layers of
+ * libs/models/resnet.py:79-95 and fpn.py:156-160, forward and data gradient.  phnet_conv3p_pack splits a weight
+ * [Co][3][3][Ci] once into its three bf16 terms, laid out in MFMA fragment order (dgrad = 0: the forward's operand;
+ * 1: the data gradient's - flipped taps, transposed channels); phnet_conv3p_fwd then computes
+ *   y = conv3x3(x, w) (+ bias) (+ addend) (ReLU)          on the dgrad = 0 packing (Ca = Ci, Nn = Co), or
+ *   dx = conv3x3_dgrad(dy, w) (+ addend)                   on the dgrad = 1 packing (x = dy, Ca = Co, Nn = Ci),
+ * same arithmetic and epilogues as phnet_conv2d_fwd_fused (stats: rows of 2*Nn floats, phnet_conv3p_stats_blocks of them).
+ * Needs Ca % 16 == 0, Nn % 64 == 0 (phnet_conv3p_applies). */
+int phnet_conv3p_applies(int64_t M, int32_t Ca, int32_t Nn);
+uint64_t phnet_conv3p_packed_bytes(int32_t Co, int32_t Ci);
+int phnet_conv3p_pack(const float* w, void* packed, int32_t Co, int32_t Ci, int32_t dgrad, void* stream);
+/* all 3x3 weights of a model in one launch: jobs = DEVICE array of njobs records {const float* w; void* dst; int32 Co, Ci, dgrad, 0;
+ * int64 first} sorted by `first` = running sum of the jobs' item counts 9*(Ca/16)*(Nn/32)*64; total = the sum of all counts */
+int phnet_conv3p_pack_jobs(const void* jobs, int32_t njobs, int64_t total, void* stream);
+uint64_t phnet_conv3p_stats_blocks(int64_t M, int32_t Ca, int32_t Nn, uint64_t ws_bytes);
+int phnet_conv3p_splits(int64_t M, int32_t Ca, int32_t Nn, uint64_t ws_bytes);
+int phnet_conv3p_fwd(const float* x, const void* packed, const float* bias, const float* addend, float* y, float* stats,
+                     int32_t N, int32_t H, int32_t W, int32_t Ca, int32_t Nn, int32_t relu,
+                     void* workspace, uint64_t ws_bytes, void* stream);
+int phnet_conv3p_tune(int32_t target_workgroups);   /* benchmarks only: workgroups a launch is topped up to by split-K */
 /* host-side query (no device work; bm/bn/splits/k_tile are HOST pointers): tile, split-K factor and K-tile depth the
  * two calls above use, i.e. the template arguments of the conv_igemm_kernel<BM, BN, DGRAD, BKT, UNI> they launch
  * (UNI = uniform-tap variant: 64x64 tile and A-side channel count % BKT == 0). */

@@ -1,3 +1,4 @@
+import os
 """Tensor-level wrappers over the C-ABI (include/phnet_hip.h): shape checks, output allocation, stream plumbing.
 
 PyTorch is used here only for device memory and the current HIP stream.  No op in this file has a
@@ -175,6 +176,84 @@ def conv2d_fwd(x, w, bias, stride: int, pad: int, relu: bool = False, out: Optio
     return out
 
 
+def conv3p_applies(m: int, ca: int, nn: int) -> bool:
+    return bool(lib().phnet_conv3p_applies(int(m), int(ca), int(nn)))
+
+
+def conv3p_pack(w: torch.Tensor, dgrad: bool, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """w OHWI [Co,3,3,Ci] f32 -> the packed operand of conv3p (three bf16 planes in MFMA fragment order, csrc/conv3p.hip)."""
+    _req(w, name="w")
+    co, r, s_, ci = w.shape
+    assert r == 3 and s_ == 3, w.shape
+    nbytes = int(lib().phnet_conv3p_packed_bytes(co, ci))
+    if out is None:
+        out = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    assert out.numel() >= nbytes and out.is_contiguous()
+    check(lib().phnet_conv3p_pack(_ptr(w), _ptr(out), co, ci, int(dgrad), _stream()), "phnet_conv3p_pack")
+    return out
+
+
+class Conv3pPackPlan:
+    """The packed images (forward + data gradient) of a list of 3x3 weights in ONE buffer, refreshed by ONE launch
+    (phnet_conv3p_pack_jobs): what a training step runs once before its first convolution.  The job table holds raw pointers:
+    it is rebuilt when a weight has moved (`matches`)."""
+
+    def __init__(self, weights, with_dgrad: bool = True):
+        """weights: contiguous OHWI tensors [Co,3,3,Ci]."""
+        dev = weights[0].device
+        self.ptrs = tuple(int(w.data_ptr()) for w in weights)
+        sizes = [int(lib().phnet_conv3p_packed_bytes(w.shape[0], w.shape[3])) for w in weights]
+        kinds = (False, True) if with_dgrad else (False,)
+        self.buf = torch.empty(sum(sizes) * len(kinds), dtype=torch.uint8, device=dev)
+        self.images, rows, off, first = [], [], 0, 0
+        for w, nbytes in zip(weights, sizes):
+            _req(w, name="w")
+            co, _, _, ci = w.shape
+            per = {}
+            for dg in kinds:
+                ca, nn = (co, ci) if dg else (ci, co)
+                assert ca % 16 == 0 and nn % 32 == 0, w.shape
+                img = self.buf[off:off + nbytes]
+                rows.append([int(w.data_ptr()), int(img.data_ptr()), co | (ci << 32), int(dg), first])
+                first += 9 * (ca // 16) * (nn // 32) * 64
+                off += nbytes
+                per[dg] = img
+            self.images.append(per)
+        self.total = first
+        self.jobs = torch.tensor(rows, dtype=torch.int64).to(dev)
+
+    def matches(self, weights) -> bool:
+        return self.ptrs == tuple(int(w.data_ptr()) for w in weights)
+
+    def refresh(self):
+        check(lib().phnet_conv3p_pack_jobs(_ptr(self.jobs), self.jobs.shape[0], self.total, _stream()), "phnet_conv3p_pack_jobs")
+
+
+def conv3p(x: torch.Tensor, packed: torch.Tensor, nn: int, dgrad: bool = False, bias=None, addend=None, relu: bool = False,
+           stats: bool = False):
+    """3x3 / stride 1 / pad 1 convolution (dgrad=False) or its data gradient (dgrad=True: x = dy) on packed weights.
+    x NHWC [N,H,W,Ca] -> NHWC [N,H,W,nn]; stats as conv2d_fwd."""
+    _req(x, name="x")
+    n, h, w_, ca = x.shape
+    out = torch.empty((n, h, w_, nn), dtype=torch.float32, device=x.device)
+    m = n * h * w_
+    need = 8 * m * nn * 4 if m * nn < (1 << 23) else 0
+    ws = workspace(need, x.device) if need else None
+    part, nblk = None, 0
+    if stats:
+        nblk = int(lib().phnet_conv3p_stats_blocks(m, ca, nn, need))
+        part = workspace(nblk * 2 * nn * 4, x.device, 1)
+    if addend is not None:
+        _req(addend, name="addend")
+        assert addend.shape == out.shape
+    _timed_launch(lambda: (f"conv3p_kernel ({'dgrad' if dgrad else 'fwd'})", int(lib().phnet_conv3p_splits(m, ca, nn, need))),
+                  2.0 * m * nn * 9 * ca,
+                  lambda: check(lib().phnet_conv3p_fwd(_ptr(x), _ptr(packed), _ptr(bias), _ptr(addend), _ptr(out), _ptr(part), n, h, w_, ca, nn,
+                                                       int(relu), _ptr(ws), need, _stream()), "phnet_conv3p_fwd"),
+                  shape=("dgrad" if dgrad else "fwd", m, nn, 9 * ca, 3))
+    return (out, (part, nblk)) if stats else out
+
+
 def conv2d_dgrad(dy, w, in_hw: Tuple[int, int], stride: int, pad: int, addend: Optional[torch.Tensor] = None):
     _req(dy, name="dy"); _req(w, name="w")
     n = dy.shape[0]
@@ -191,6 +270,7 @@ def conv2d_dgrad(dy, w, in_hw: Tuple[int, int], stride: int, pad: int, addend: O
     return dx
 
 
+CONV3P = os.environ.get("PHNET_CONV3P", "1") != "0"           # packed-weight 3x3 kernel for the trunk / FPN forward and data gradient (trunk.packed_path); bench A/B switch
 _WGRAD3 = True          # mirrors csrc/conv.hip g_wgrad3 (kernel names of the bench's per-kernel accounting only)
 
 

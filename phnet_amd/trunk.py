@@ -48,15 +48,47 @@ def _sync_bn(bn) -> bool:
 
 class _ConvBN:
     """Tape record of conv -> BN(+residual)(+ReLU)."""
-    __slots__ = ("conv", "bn", "stride", "pad", "x_in", "w", "c", "y", "sm", "si", "relu", "has_res", "sync_count")
+    __slots__ = ("conv", "bn", "stride", "pad", "x_in", "w", "c", "y", "sm", "si", "relu", "has_res", "sync_count", "packed")
 
 
-def _conv_bn(tape: list, x, conv: nn.Conv2d, bn, training: bool, relu: bool, residual=None, w_override=None):
+def _is3x3s1(conv: nn.Conv2d) -> bool:
+    return (conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1)
+            and conv.groups == 1 and conv.in_channels % 16 == 0 and conv.out_channels % 64 == 0 and conv.in_channels % 64 == 0)
+
+
+def packed_path() -> bool:
+    """The packed-weight 3x3 kernel (csrc/conv3p.hip) runs in the default GEMM arithmetic only."""
+    return K._MMA_MODE == 3 and K.CONV3P
+
+
+def _pack_plan(enc, convs):
+    """Packed images (forward + data gradient) of every 3x3 / stride-1 weight of the encoder, refreshed by ONE launch per
+    training step; {id(conv): {False: forward image, True: dgrad image}}."""
+    weights = [ohwi(c.weight) for c in convs]
+    plan = enc.__dict__.get("_phnet_pack_plan")
+    if plan is None or not plan.matches(weights):
+        if plan is not None:                                   # a captured hipGraph may still write the old images: retire, never free
+            enc.__dict__.setdefault("_phnet_pack_retired", []).append(plan)
+        plan = K.Conv3pPackPlan(weights)
+        enc.__dict__["_phnet_pack_plan"] = plan
+    plan.refresh()
+    return {id(c): img for c, img in zip(convs, plan.images)}
+
+
+def _conv3(x, w, packed, stats=False, bias=None, addend=None, relu=False):
+    """3x3 / stride-1 forward: the packed-weight kernel when an image is at hand, else the generic entry point."""
+    if packed is not None:
+        return K.conv3p(x, packed[False], w.shape[0], bias=bias, addend=addend, relu=relu, stats=stats)
+    return K.conv2d_fwd(x, w, bias, 1, 1, relu=relu, addend=addend, stats=stats)
+
+
+def _conv_bn(tape: list, x, conv: nn.Conv2d, bn, training: bool, relu: bool, residual=None, w_override=None, packs=None):
     rec = _ConvBN()
     rec.conv, rec.bn = conv, bn
     rec.stride, rec.pad = conv.stride[0], conv.padding[0]
     rec.w = w_override if w_override is not None else ohwi(conv.weight)
     rec.x_in = x
+    rec.packed = packs.get(id(conv)) if packs is not None else None
     mom = bn.momentum if bn.momentum is not None else 0.1
     rec.sync_count = None
     rec.relu, rec.has_res = relu, residual is not None
@@ -64,12 +96,17 @@ def _conv_bn(tape: list, x, conv: nn.Conv2d, bn, training: bool, relu: bool, res
         # eval: scale / shift of the running statistics folded into the weights and a bias (cached until a parameter or a
         # statistic changes), residual add and ReLU in the GEMM epilogue - ONE launch per conv/BN/ReLU block, no
         # elementwise pass (resnet.py:79-95 in eval mode: y = relu(bn(conv(x)) + identity))
-        wf, bf = _folded(conv, bn, rec.w)
-        rec.c = rec.y = K.conv2d_fwd(x, wf, bf, rec.stride, rec.pad, relu=relu, addend=residual)
+        wf, bf, pk = _folded(conv, bn, rec.w)
+        if pk is not None:
+            rec.c = rec.y = K.conv3p(x, pk, wf.shape[0], bias=bf, addend=residual, relu=relu)
+        else:
+            rec.c = rec.y = K.conv2d_fwd(x, wf, bf, rec.stride, rec.pad, relu=relu, addend=residual)
         rec.sm = rec.si = None
     elif training and _sync_bn(bn):
         co = rec.w.shape[0]
-        if co <= 1024 and (co & (co - 1)) == 0:                   # local statistics from the convolution's own epilogue, as below
+        if rec.packed is not None and co <= 1024 and (co & (co - 1)) == 0:
+            rec.c, partials = _conv3(x, rec.w, rec.packed, stats=True)
+        elif co <= 1024 and (co & (co - 1)) == 0:                   # local statistics from the convolution's own epilogue, as below
             rec.c, partials = K.conv2d_fwd(x, rec.w, None, rec.stride, rec.pad, stats=True)
         else:
             rec.c, partials = K.conv2d_fwd(x, rec.w, None, rec.stride, rec.pad), None
@@ -80,7 +117,9 @@ def _conv_bn(tape: list, x, conv: nn.Conv2d, bn, training: bool, relu: bool, res
         # training: the batch statistics come out of the convolution's own epilogue (per-slab partial sums), no second pass
         co = rec.w.shape[0]
         fused_stats = training and co <= 1024 and (co & (co - 1)) == 0
-        if fused_stats:
+        if fused_stats and rec.packed is not None:
+            rec.c, partials = _conv3(x, rec.w, rec.packed, stats=True)
+        elif fused_stats:
             rec.c, partials = K.conv2d_fwd(x, rec.w, None, rec.stride, rec.pad, stats=True)
         else:
             rec.c, partials = K.conv2d_fwd(x, rec.w, None, rec.stride, rec.pad), None
@@ -103,30 +142,39 @@ def weights_changed():
 def _folded(conv: nn.Conv2d, bn, w_ohwi: torch.Tensor):
     """(w * gamma / sqrt(var + eps) per output channel, beta - mean * gamma / sqrt(var + eps)) for an eval-mode conv -> BN pair.
     Cached ON the BatchNorm module (dies with the model), valid while no tensor version moved and no raw-pointer writer ran."""
-    ver = (_WEIGHT_EPOCH[0], conv.weight._version, bn.weight._version, bn.bias._version, bn.running_mean._version,
+    ver = (_WEIGHT_EPOCH[0], packed_path(), conv.weight._version, bn.weight._version, bn.bias._version, bn.running_mean._version,
            bn.running_var._version, conv.weight.data_ptr(), bn.running_mean.data_ptr(), w_ohwi.shape)
     hit = bn.__dict__.get("_phnet_fold")
     if hit is not None and hit[0] == ver:
-        return hit[1], hit[2]
+        return hit[1], hit[2], hit[3]
     with torch.no_grad():
         scale = bn.weight.detach() * torch.rsqrt(bn.running_var + bn.eps)
         wf = (w_ohwi.reshape(w_ohwi.shape[0], -1) * scale[:, None]).reshape(w_ohwi.shape).contiguous()
         bf = (bn.bias.detach() - bn.running_mean * scale).contiguous()
-    bn.__dict__["_phnet_fold"] = (ver, wf, bf)
-    return wf, bf
+        pk = K.conv3p_pack(wf, False) if (_is3x3s1(conv) and packed_path() and w_ohwi.shape[1] == 3) else None
+    bn.__dict__["_phnet_fold"] = (ver, wf, bf, pk)
+    return wf, bf, pk
 
 
 class _Tape:
     """What the backward schedule needs from the forward."""
-    __slots__ = ("enc", "tape", "argmax", "stem_shape", "feats", "lats", "lat_w", "out_w", "index", "nparams")
+    __slots__ = ("enc", "tape", "argmax", "stem_shape", "feats", "lats", "lat_w", "out_w", "out_packs", "index", "nparams")
 
 
 def encoder_fwd_schedule(enc, training: bool, frames: torch.Tensor):
     """(P3, P4, P5) NHWC and, in training, the tape for `encoder_bwd_schedule`."""
     model, neck = enc.backbone.model, enc.neck
     tape = []
+    packs = None
     if training:
         weights_changed()                                      # running statistics are about to move (raw-pointer writes)
+        if packed_path():
+            # every 3x3 / stride-1 weight of the trunk and the neck split into bf16 planes in MFMA fragment order, forward and
+            # data-gradient images, by ONE launch: the GEMM loops fetch them straight into registers (csrc/conv3p.hip)
+            convs = [m for m in model.modules() if isinstance(m, nn.Conv2d) and _is3x3s1(m)]
+            convs += [m.conv for m in neck.fpn_convs if _is3x3s1(m.conv)]
+            if convs:
+                packs = _pack_plan(enc, convs)
     x = K.nchw3_to_nhwc4(frames.contiguous())
     w_stem = K.pad_channels(ohwi(model.conv1.weight).view(-1, 3), 4).view(model.conv1.out_channels, 7, 7, 4)
     y = _conv_bn(tape, x, model.conv1, model.bn1, training, relu=True, w_override=w_stem)
@@ -135,12 +183,12 @@ def encoder_fwd_schedule(enc, training: bool, frames: torch.Tensor):
     stages = []
     for name in ("layer1", "layer2", "layer3", "layer4"):
         for blk in getattr(model, name):
-            h = _conv_bn(tape, y, blk.conv1, blk.bn1, training, relu=True)
+            h = _conv_bn(tape, y, blk.conv1, blk.bn1, training, relu=True, packs=packs)
             if blk.downsample is not None:
-                idn = _conv_bn(tape, y, blk.downsample[0], blk.downsample[1], training, relu=False)
+                idn = _conv_bn(tape, y, blk.downsample[0], blk.downsample[1], training, relu=False, packs=packs)
             else:
                 idn = y
-            y = _conv_bn(tape, h, blk.conv2, blk.bn2, training, relu=True, residual=idn)
+            y = _conv_bn(tape, h, blk.conv2, blk.bn2, training, relu=True, residual=idn, packs=packs)
         stages.append(y)
     feats = stages[-3:]                                        # fpn.py:113-115 drops layer1
     lat_w = [ohwi(m.conv.weight) for m in neck.lateral_convs]
@@ -148,7 +196,8 @@ def encoder_fwd_schedule(enc, training: bool, frames: torch.Tensor):
     lats = [K.conv2d_fwd(f, w, m.conv.bias.detach(), 1, 0) for f, w, m in zip(feats, lat_w, neck.lateral_convs)]
     for i in (2, 1):
         K.upsample_add_(lats[i - 1], lats[i])
-    outs = [K.conv2d_fwd(l, w, m.conv.bias.detach(), 1, 1) for l, w, m in zip(lats, out_w, neck.fpn_convs)]
+    out_packs = [packs.get(id(m.conv)) if packs is not None else None for m in neck.fpn_convs]
+    outs = [_conv3(l, w, pk, bias=m.conv.bias.detach()) for l, w, m, pk in zip(lats, out_w, neck.fpn_convs, out_packs)]
     ctx = None
     if training:
         counters = [r.bn.num_batches_tracked for r in tape if r.bn.num_batches_tracked is not None]
@@ -156,7 +205,7 @@ def encoder_fwd_schedule(enc, training: bool, frames: torch.Tensor):
             torch._foreach_add_(counters, 1)               # one multi-tensor launch for the 36 BatchNorm step counters
         ctx = _Tape()
         ctx.enc, ctx.tape, ctx.argmax, ctx.stem_shape = enc, tape, argmax, stem_shape
-        ctx.feats, ctx.lats, ctx.lat_w, ctx.out_w = feats, lats, lat_w, out_w
+        ctx.feats, ctx.lats, ctx.lat_w, ctx.out_w, ctx.out_packs = feats, lats, lat_w, out_w, out_packs
         ctx.index = {id(p): i for i, p in enumerate(enc.parameters())}
         ctx.nparams = len(ctx.index)
     return tuple(outs), ctx
@@ -224,7 +273,10 @@ def encoder_bwd_schedule(ctx: _Tape, d3, d4, d5, stage_done: Optional[Callable[[
     for i in range(3):
         m = neck.fpn_convs[i].conv
         conv_wgrad_into(m.weight, douts[i], ctx.lats[i], ctx.out_w[i].shape, 1, 1, bias=m.bias)
-        dl.append(K.conv2d_dgrad(douts[i], ctx.out_w[i], tuple(ctx.lats[i].shape[1:3]), 1, 1))
+        if ctx.out_packs[i] is not None:
+            dl.append(K.conv3p(douts[i], ctx.out_packs[i][True], ctx.out_w[i].shape[3], dgrad=True))
+        else:
+            dl.append(K.conv2d_dgrad(douts[i], ctx.out_w[i], tuple(ctx.lats[i].shape[1:3]), 1, 1))
     for i in (1, 2):
         K.upsample_add_bwd_(dl[i - 1], dl[i])
     dstage = []
@@ -266,6 +318,8 @@ def encoder_bwd_schedule(ctx: _Tape, d3, d4, d5, stage_done: Optional[Callable[[
             conv_wgrad_into(rec.conv.weight, dc, rec.x_in, rec.w.shape, rec.stride, rec.pad)
         if not need_dx:
             return None
+        if rec.packed is not None:
+            return K.conv3p(dc, rec.packed[True], rec.w.shape[3], dgrad=True, addend=addend)
         return K.conv2d_dgrad(dc, rec.w, tuple(rec.x_in.shape[1:3]), rec.stride, rec.pad, addend)
 
     dy = None

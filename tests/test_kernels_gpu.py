@@ -256,6 +256,47 @@ def test_conv_fwd_dgrad_wgrad_bf16x3(ops, bf16x3, case):
     close(dw, 2 * w.grad.permute(0, 2, 3, 1), 2e-5)
 
 
+@pytest.mark.parametrize("case", [(2, 16, 20, 64, 64), (3, 5, 17, 64, 128), (4, 2, 5, 512, 512), (1, 1, 70, 64, 64), (5, 20, 50, 256, 64),
+                                  (1, 10, 25, 512, 512), (4, 3, 23, 128, 64), (3, 8, 20, 128, 128), (2, 2, 2, 64, 64), (1, 40, 100, 64, 192)])
+def test_packed_weight_3x3_kernel_vs_fp64(ops, bf16x3, case):
+    """conv3p_kernel (csrc/conv3p.hip: 3x3 / stride 1 / pad 1 on weights packed into bf16 planes in MFMA fragment order), forward
+    and data gradient: image rows narrower / wider than the 128-pixel block, blocks that span image rows and frames, one- and
+    two-row images (every row a border row), ragged pixel counts, split-K and unsplit plans, bias / addend / ReLU epilogues,
+    the BatchNorm statistics rows, the batched pack launch - against fp64 at the tolerance of the generic kernel (2e-5 of the
+    output scale) and against the generic entry points."""
+    N, Hi, Wi, Ci, Co = case
+    torch.manual_seed(sum(case) + 5)
+    x = torch.randn(N, Ci, Hi, Wi, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn(Co, Ci, 3, 3, dtype=torch.float64) / (Ci * 9) ** 0.5).requires_grad_(True)
+    b = torch.randn(Co, dtype=torch.float64)
+    res = torch.randn(N, Co, Hi, Wi, dtype=torch.float64)
+    ref = F.conv2d(x, w, None, stride=1, padding=1)
+    gy = torch.randn_like(ref)
+    ref.backward(gy)
+    xd, wd, gyd = nhwc(x.detach().float()), nhwc(w.detach().float()), nhwc(gy.float())
+    assert ops.conv3p_applies(N * Hi * Wi, Ci, Co) and ops.conv3p_applies(N * Hi * Wi, Co, Ci)
+    pf, pd = ops.conv3p_pack(wd, False), ops.conv3p_pack(wd, True)
+    plan = ops.Conv3pPackPlan([wd, wd * 2.0])                       # the one-launch form over several weights
+    plan.refresh()
+    assert torch.equal(plan.images[0][False], pf) and torch.equal(plan.images[0][True], pd)
+    assert torch.equal(plan.images[1][False].view(torch.int16), ops.conv3p_pack(wd * 2.0, False).view(torch.int16))
+    want = ref.permute(0, 2, 3, 1)
+    close(ops.conv3p(xd, pf, Co), want, 2e-5)
+    close(ops.conv3p(xd, pf, Co, bias=dev(b.float()), addend=nhwc(res.float()), relu=True),
+          F.relu(ref + b[None, :, None, None] + res).permute(0, 2, 3, 1), 2e-5)
+    close(ops.conv3p(gyd, pd, Ci, dgrad=True), x.grad.permute(0, 2, 3, 1), 2e-5)
+    close(ops.conv3p(gyd, pd, Ci, dgrad=True, addend=xd), (x.grad + x.detach()).permute(0, 2, 3, 1), 2e-5)
+    if Co & (Co - 1) == 0:
+        y, (part, nblk) = ops.conv3p(xd, pf, Co, stats=True)
+        close(y, want, 2e-5)
+        sums = part[:nblk * 2 * Co * 4].view(torch.float32).view(nblk, 2, Co).double().sum(0).cpu()
+        assert float((sums[0] - ref.sum((0, 2, 3))).abs().max()) <= 2e-5 * float(ref.abs().sum((0, 2, 3)).max())
+        assert float((sums[1] - (ref ** 2).sum((0, 2, 3))).abs().max()) <= 2e-5 * float((ref ** 2).sum((0, 2, 3)).max())
+    # and the entry points it replaces in the trunk schedule
+    close(ops.conv3p(xd, pf, Co), ops.conv2d_fwd(xd, wd, None, 1, 1).double().cpu(), 2e-5)
+    close(ops.conv3p(gyd, pd, Ci, dgrad=True), ops.conv2d_dgrad(gyd, wd, (Hi, Wi), 1, 1).double().cpu(), 2e-5)
+
+
 @pytest.mark.parametrize("case", [(2, 16, 20, 64, 64), (3, 5, 17, 64, 128), (2, 7, 16, 128, 64), (1, 1, 70, 64, 64), (5, 20, 50, 256, 64),
                                   (1, 10, 25, 512, 512), (4, 3, 23, 64, 64)])
 def test_wgrad_three_taps_kernel_vs_fp64(ops, bf16x3, case):

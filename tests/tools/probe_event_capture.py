@@ -42,18 +42,31 @@ def main():
         ev.record(s)
     torch.cuda.synchronize()
     res = {"A_idle": query_in_thread(ev)}
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g, stream=other, capture_error_mode="thread_local"):
-        x.add_(1.0)
-        res["B_other_stream_capturing"] = query_in_thread(ev)
-    g2 = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g2, stream=other, capture_error_mode="thread_local"):
-        x.add_(1.0)
-        s.wait_stream(other)                                    # S joins the capture (what ncclStream does for a captured collective)
-        with torch.cuda.stream(s):
-            x.mul_(1.0)
-        res["C_its_stream_joined_the_capture"] = query_in_thread(ev)
-        other.wait_stream(s)
+    print(json.dumps(res), flush=True)
+    try:
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=other, capture_error_mode="thread_local"):
+            x.add_(1.0)
+            res["B_other_stream_capturing"] = query_in_thread(ev)
+    except Exception as e:                                      # noqa: BLE001
+        res["B_capture_error"] = str(e).split("\n")[0][:160]
+    print(json.dumps(res), flush=True)
+    try:
+        g2 = torch.cuda.CUDAGraph()
+        fork, join = torch.cuda.Event(), torch.cuda.Event()
+        with torch.cuda.graph(g2, stream=other, capture_error_mode="thread_local"):
+            x.add_(1.0)
+            fork.record(other)
+            s.wait_event(fork)                                  # S joins the capture (what ncclStream does for a captured collective)
+            with torch.cuda.stream(s):
+                x.mul_(1.0)
+                join.record(s)
+            other.wait_event(join)
+            x.add_(1.0)
+            res["C_its_stream_joined_the_capture"] = query_in_thread(ev)
+    except Exception as e:                                      # noqa: BLE001
+        res["C_capture_error"] = str(e).split("\n")[0][:160]
+    print(json.dumps(res), flush=True)
     torch.cuda.synchronize()
     res["D_after_capture"] = query_in_thread(ev)
     print(json.dumps(res), flush=True)
