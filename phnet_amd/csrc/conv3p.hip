@@ -247,21 +247,20 @@ __global__ __launch_bounds__(P3_THREADS, 3) void conv3p_kernel(
         }
     }
 
-    // ---- per-channel statistics of the result for a following BatchNorm: one (sum, sum of squares) row per 32-row slab ----
+    // ---- per-channel statistics of the result for a following BatchNorm: one (sum, sum of squares) row per 64-row wave tile ----
     if (stats != nullptr && final_pass) {
         const int n = n0 + wn + frag_col(lane);
+        float sm = 0.f, sq = 0.f;
 #pragma unroll
-        for (int f = 0; f < 2; ++f) {
-            float sm = 0.f, sq = 0.f;
+        for (int f = 0; f < 2; ++f)
 #pragma unroll
             for (int e = 0; e < 16; ++e) { const float v = acc[f][0][e]; sm += v; sq += v * v; }
-            sm += __shfl_xor(sm, 32, 64);
-            sq += __shfl_xor(sq, 32, 64);
-            if (lane < 32) {
-                float* p = stats + (size_t)((m0 + wm + 32 * f) >> 5) * 2 * g.Nn;
-                p[n] = sm;
-                p[g.Nn + n] = sq;
-            }
+        sm += __shfl_xor(sm, 32, 64);
+        sq += __shfl_xor(sq, 32, 64);
+        if (lane < 32) {
+            float* p = stats + (size_t)((m0 + wm) >> 6) * 2 * g.Nn;
+            p[n] = sm;
+            p[g.Nn + n] = sq;
         }
     }
     float* dst = out + (size_t)blockIdx.z * M * g.Nn;
@@ -378,7 +377,7 @@ PHNET_API uint64_t phnet_conv3p_stats_blocks(int64_t M, int32_t Ca, int32_t Nn, 
 {
     if (!p3_applies((long)M, Ca, Nn)) return 0;
     const P3Plan p = p3_plan((long)M, Ca, Nn, (size_t)ws_bytes);
-    return (uint64_t)(p.splits > 1 ? cdiv((long)M * Nn / 4, 256) : cdiv((long)M, P3_BM) * (P3_BM / 32));
+    return (uint64_t)(p.splits > 1 ? cdiv((long)M * Nn / 4, 256) : cdiv((long)M, P3_BM) * (P3_BM / 64));
 }
 
 PHNET_API int phnet_conv3p_splits(int64_t M, int32_t Ca, int32_t Nn, uint64_t ws_bytes)

@@ -246,7 +246,7 @@ def conv3p(x: torch.Tensor, packed: torch.Tensor, nn: int, dgrad: bool = False, 
     if addend is not None:
         _req(addend, name="addend")
         assert addend.shape == out.shape
-    _timed_launch(lambda: (f"conv3p_kernel ({'dgrad' if dgrad else 'fwd'})", int(lib().phnet_conv3p_splits(m, ca, nn, need))),
+    _timed_launch(lambda: ("conv3p_kernel", int(lib().phnet_conv3p_splits(m, ca, nn, need))),        # one symbol, as rocprofv3 sees it
                   2.0 * m * nn * 9 * ca,
                   lambda: check(lib().phnet_conv3p_fwd(_ptr(x), _ptr(packed), _ptr(bias), _ptr(addend), _ptr(out), _ptr(part), n, h, w_, ca, nn,
                                                        int(relu), _ptr(ws), need, _stream()), "phnet_conv3p_fwd"),

@@ -179,6 +179,18 @@ def make_state(g: O.Geometry) -> "OrderedDict[str, torch.Tensor]":
     return OrderedDict((k, sd[k]) for k in state_spec(g))
 
 
+def calibrate_running_stats_(sd, frames: torch.Tensor, arch: str, bn_eps: float = 1e-5):
+    """Replaces the trunk's BatchNorm running statistics (synthetic N(0, 0.1) / U(0.5, 1.5) values that no real checkpoint would
+    hold: under them the eval-mode trunk does not normalise and its activations grow to 3.5e4 over 34 layers) by the batch
+    statistics of `frames` - one training-mode pass of the oracle's trunk with momentum 1.  Eval activations are then O(1-10),
+    as with trained weights, and comparisons against the oracle on this state need no allowance for the rounding of huge
+    intermediate values.  In place; returns sd.  (Only for tests that compare against the ORACLE run on the same state - the
+    fixtures produced by the reference were generated with the uncalibrated statistics and keep them.)"""
+    with torch.no_grad():
+        O.resnet_trunk(sd, frames, O.Geometry(arch=arch, bn_eps=bn_eps, bn_momentum=1.0), True, True)
+    return sd
+
+
 def make_clip(g: O.Geometry, T: int, seed: int = 3407) -> torch.Tensor:
     r = np.random.default_rng([seed, T, g.img_h, g.img_w])
     return torch.from_numpy(r.standard_normal((T, 3, g.img_h, g.img_w), dtype=np.float32))

@@ -47,17 +47,15 @@ def _build(g: O.Geometry):
     return model.cuda()
 
 
-def _close(a, b, tol=ACT_TOL, what="", ulp_floor=0.0):
-    """|a - b| <= tol * (1 + |b|) element-wise.  ulp_floor: additional allowance in units of 2^-23 * max|b| for tensors whose
-    elements are sums of terms of the tensor's LARGEST magnitude (conv outputs under the synthetic eval statistics reach
-    3.5e4: one fp32 rounding of such a term is 4e-3, whatever the implementation)."""
+def _close(a, b, tol=ACT_TOL, what=""):
+    """|a - b| <= tol * (1 + |b|) element-wise."""
     a = torch.as_tensor(a).detach().cpu().double()
     b = torch.as_tensor(b).detach().cpu().double()
     assert a.shape == b.shape, (what, a.shape, b.shape)
     if b.numel() == 0:
         return
     err = (a - b).abs()
-    bound = tol * (1.0 + b.abs()) + ulp_floor * 2.0 ** -23 * float(b.abs().max())
+    bound = tol * (1.0 + b.abs())
     bad = err > bound
     assert not bool(bad.any()), (what, float(err.max()), int(bad.sum()), float(b.abs().max()))
 
@@ -394,12 +392,18 @@ def test_every_stage_teacher_forced_vs_oracle(geom, training):
     model.train(training)
     sd = synth.make_state(g)
     frames, lanes = synth.make_clip(g, T), synth.make_targets(g, T)
+    if not training:
+        # eval: running statistics that match the weights (tests/synth.py calibrate_running_stats_) - activations O(1-10) as with a
+        # trained checkpoint, so the FPN maps are held to the same strict bound as everything else (round 2 needed an allowance of
+        # 32 ulp of the largest value because the synthetic statistics let the eval trunk grow to 3.5e4)
+        synth.calibrate_running_stats_(sd, frames, g.arch)
+        model.load_state_dict(sd, strict=True)
     col = {}
     with torch.no_grad():
         O.clip_forward(sd, frames, lanes if training else None, g, training, nms_fn=ON.lane_nms, collect=col)
         feats = model.backbone(frames.cuda())
         for j in range(3):
-            _close(feats[j].permute(0, 3, 1, 2), col["fpn"][j], what=f"fpn{j}", ulp_floor=32.0)
+            _close(feats[j].permute(0, 3, 1, 2), col["fpn"][j], what=f"fpn{j}")
         det = model.detNet
         for t in range(T):
             fo = col["frames"][t]
