@@ -27,7 +27,7 @@ struct P3Shape {
     int splits, units_per_split;   // split-K over units (filter row, 16-channel chunk), blockIdx.z
 };
 
-constexpr int P3_BM = 128, P3_BN = 64, P3_ROWS = P3_BM + 2, P3_THREADS = 256;
+constexpr int P3_BM = 128, P3_ROWS = P3_BM + 2, P3_THREADS = 256;      // columns per workgroup: 64 * FN (template)
 constexpr int P3_APITCH = 48;                                 // bytes: 16 bf16 + 16 pad (conflict-free ds_read_b128, igemm.h KContigPlanes)
 constexpr int P3_ZROW = P3_ROWS;                              // one more row per plane that stays zero: where border lanes read
 constexpr int P3_APLANE = (P3_ROWS + 1) * P3_APITCH, P3_AIMG = 3 * P3_APLANE;
@@ -90,7 +90,8 @@ __global__ __launch_bounds__(256) void conv3p_pack_jobs_kernel(const P3PackJob* 
     conv3p_pack_item(jb.w, jb.dst, jb.Co, jb.Ci, jb.dgrad, i - jb.first);
 }
 
-__global__ __launch_bounds__(P3_THREADS, 3) void conv3p_kernel(
+template <int FN>
+__global__ __launch_bounds__(P3_THREADS, FN == 1 ? 3 : 2) void conv3p_kernel(
     const float* __restrict__ X, const unsigned char* __restrict__ Bp, const float* __restrict__ bias,
     const float* __restrict__ addend, float* __restrict__ out, P3Shape g, int relu, float* __restrict__ stats)
 {
@@ -101,12 +102,13 @@ __global__ __launch_bounds__(P3_THREADS, 3) void conv3p_kernel(
     const int W = g.W, H = g.H, Ca = g.Ca;
     const int M = g.N * H * W;
     const int CC = Ca >> 4, NF = g.Nn >> 5;
-    const int tiles_n = g.Nn >> 6;
+    constexpr int BN = 64 * FN;
+    const int tiles_n = g.Nn / BN;
     const unsigned tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (int)(tile / tiles_n) * P3_BM, n0 = (int)(tile % tiles_n) * P3_BN;
+    const int m0 = (int)(tile / tiles_n) * P3_BM, n0 = (int)(tile % tiles_n) * BN;
     const int u_begin = blockIdx.z * g.units_per_split, u_end = min(3 * CC, u_begin + g.units_per_split);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 32;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 32 * FN;
 
     constexpr unsigned OOB = 0x80000000u;
     __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)min((long)M * Ca * 4, (long)0x7fffffff), 0x00020000);
@@ -166,31 +168,38 @@ __global__ __launch_bounds__(P3_THREADS, 3) void conv3p_kernel(
     const int b_step = NF * 3 * 64 * 16;                     // bytes per step
     int lb_q = u_begin * 3;                                   // next step to load
     const int q_end = u_end * 3;
-    auto load_b = [&](Frag3& f) {
-        const int off = lb_q < q_end ? b_lane + lb_q * b_step : (int)OOB;
-        f.hi = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, off, 0, 0));
-        f.mid = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, lb_q < q_end ? off + 1024 : (int)OOB, 0, 0));
-        f.lo = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, lb_q < q_end ? off + 2048 : (int)OOB, 0, 0));
+    auto load_b = [&](Frag3 (&f)[FN]) {
+        const bool ok = lb_q < q_end;
+        const int off = b_lane + lb_q * b_step;
+#pragma unroll
+        for (int jn = 0; jn < FN; ++jn) {
+            f[jn].hi = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, ok ? off + jn * 3072 : (int)OOB, 0, 0));
+            f[jn].mid = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, ok ? off + jn * 3072 + 1024 : (int)OOB, 0, 0));
+            f[jn].lo = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, ok ? off + jn * 3072 + 2048 : (int)OOB, 0, 0));
+        }
         ++lb_q;
     };
 
     // accumulators start from bias (+ addend) when this launch is the final pass
     const bool final_pass = g.splits == 1;
-    f32x16 acc[2][1];
+    f32x16 acc[2][FN];
     {
         // (branch-free: out-of-range rows and a missing addend read zeros through the buffer descriptor)
-        const int n = n0 + wn + frag_col(lane);
-        const float bv = (final_pass && bias) ? bias[n] : 0.f;
         const bool use_add = final_pass && addend != nullptr;
         __amdgpu_buffer_rsrc_t add_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)addend, 0, use_add ? (int)min((long)M * g.Nn * 4, (long)0x7fffffff) : 0, 0x00020000);
 #pragma unroll
-        for (int f = 0; f < 2; ++f)
+        for (int jn = 0; jn < FN; ++jn) {
+            const int n = n0 + wn + 32 * jn + frag_col(lane);
+            const float bv = (final_pass && bias) ? bias[n] : 0.f;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + wm + 32 * f + frag_row(lane, e);
-                const int off = (use_add && m < M) ? (m * g.Nn + n) * 4 : (int)OOB;
-                acc[f][0][e] = bv + __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(add_rsrc, off, 0, 0));
-            }
+            for (int f = 0; f < 2; ++f)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = m0 + wm + 32 * f + frag_row(lane, e);
+                    const int off = (use_add && m < M) ? (m * g.Nn + n) * 4 : (int)OOB;
+                    acc[f][jn][e] = bv + __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(add_rsrc, off, 0, 0));
+                }
+        }
     }
     // A fragment addresses per (fragment, tap), relative to the image: row wm + 32 f + r + dx of the lane's pixel - or, where the tap
     // leaves the image row on that pixel (x = 0 for dx = 0, x = W-1 for dx = 2), the image's zero row: no masking in the loop
@@ -212,7 +221,7 @@ __global__ __launch_bounds__(P3_THREADS, 3) void conv3p_kernel(
 
     if (u_begin < u_end) {
         f32x4 a_reg[3];
-        Frag3 bq[P3_PFB];
+        Frag3 bq[P3_PFB][FN];
         load_a(a_reg);
 #pragma unroll
         for (int d = 0; d < P3_PFB; ++d) load_b(bq[d]);
@@ -230,8 +239,7 @@ __global__ __launch_bounds__(P3_THREADS, 3) void conv3p_kernel(
                 a[f].mid = *reinterpret_cast<const bf16x8*>(p + P3_APLANE);
                 a[f].lo = *reinterpret_cast<const bf16x8*>(p + 2 * P3_APLANE);
             }
-            Frag3 (&b)[1] = reinterpret_cast<Frag3 (&)[1]>(bq[dxi]);
-            mma3_step<2, 1>(a, b, acc);
+            mma3_step<2, FN>(a, bq[dxi], acc);
             load_b(bq[dxi]);                                  // the slot takes the fragment three steps ahead
         };
         for (int u = u_begin; u < u_end; ++u) {
@@ -249,29 +257,35 @@ __global__ __launch_bounds__(P3_THREADS, 3) void conv3p_kernel(
 
     // ---- per-channel statistics of the result for a following BatchNorm: one (sum, sum of squares) row per 64-row wave tile ----
     if (stats != nullptr && final_pass) {
-        const int n = n0 + wn + frag_col(lane);
-        float sm = 0.f, sq = 0.f;
 #pragma unroll
-        for (int f = 0; f < 2; ++f)
+        for (int jn = 0; jn < FN; ++jn) {
+            const int n = n0 + wn + 32 * jn + frag_col(lane);
+            float sm = 0.f, sq = 0.f;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) { const float v = acc[f][0][e]; sm += v; sq += v * v; }
-        sm += __shfl_xor(sm, 32, 64);
-        sq += __shfl_xor(sq, 32, 64);
-        if (lane < 32) {
-            float* p = stats + (size_t)((m0 + wm) >> 6) * 2 * g.Nn;
-            p[n] = sm;
-            p[g.Nn + n] = sq;
+            for (int f = 0; f < 2; ++f)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { const float v = acc[f][jn][e]; sm += v; sq += v * v; }
+            sm += __shfl_xor(sm, 32, 64);
+            sq += __shfl_xor(sq, 32, 64);
+            if (lane < 32) {
+                float* p = stats + (size_t)((m0 + wm) >> 6) * 2 * g.Nn;
+                p[n] = sm;
+                p[g.Nn + n] = sq;
+            }
         }
     }
     float* dst = out + (size_t)blockIdx.z * M * g.Nn;
-    const int n = n0 + wn + frag_col(lane);
 #pragma unroll
-    for (int f = 0; f < 2; ++f)
+    for (int jn = 0; jn < FN; ++jn) {
+        const int n = n0 + wn + 32 * jn + frag_col(lane);
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int m = m0 + wm + 32 * f + frag_row(lane, e);
-            if (m < M) dst[(size_t)m * g.Nn + n] = (final_pass && relu) ? fmaxf(acc[f][0][e], 0.f) : acc[f][0][e];
-        }
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm + 32 * f + frag_row(lane, e);
+                if (m < M) dst[(size_t)m * g.Nn + n] = (final_pass && relu) ? fmaxf(acc[f][jn][e], 0.f) : acc[f][jn][e];
+            }
+    }
 }
 
 // out[i] = sum_z part[z][i] (+bias) (+addend) (relu); optionally the BatchNorm statistics rows of the result (conv.hip's
@@ -315,19 +329,26 @@ __global__ __launch_bounds__(256) void conv3p_reduce_kernel(const float* __restr
 
 inline long cdiv(long a, long b) { return (a + b - 1) / b; }
 
-int g_p3_target = 700;          // workgroups a launch is topped up to by split-K (tuning aid: phnet_conv3p_tune)
+int g_p3_target = 512;          // workgroups a launch is topped up to by split-K (tuning aid: phnet_conv3p_tune): two per CU, evenly
+int g_p3_wide = 1;              // 128-column workgroup tile (64 x 64 per wave) where the output has >= 128 channels
 
-struct P3Plan { long tiles; int splits, units_per_split; };
+struct P3Plan { long tiles; int fn, splits, units_per_split; };
 
+// Measured on MI355X (tests/tools/bench_conv3p.py, one 5-frame clip): what matters at these sizes is that the workgroups of a
+// launch spread EVENLY over the 256 CUs - 480 workgroups (two per CU, all resident) beat 640 (three on some CUs, two on others)
+// by 8-15 % on layer3 / layer4 - so split-K tops the grid up to at most `target`, never beyond it.
 P3Plan p3_plan(long M, int Ca, int Nn, size_t ws_bytes)
 {
     P3Plan p;
-    p.tiles = cdiv(M, P3_BM) * (Nn / P3_BN);
+    // the 128-column tile halves the A-side LDS traffic per MFMA but doubles the weight bytes a wave streams per step: measured
+    // +4 % on layer2 (20000 pixels x 128), nothing on layer3, -15 % on layer4 (1250 x 512: few tiles, 14 MB of weights)
+    p.fn = (g_p3_wide && Nn % 128 == 0 && M >= 16384) ? 2 : 1;
+    p.tiles = cdiv(M, P3_BM) * (Nn / (64 * p.fn));
     const int units = 3 * (Ca / 16);
     int splits = 1;
-    if (ws_bytes > 0 && p.tiles < (g_p3_target * 3) / 4) {
-        splits = (int)min((long)8, max((long)1, (g_p3_target + p.tiles / 2) / p.tiles));
-        while (splits > 1 && units / splits < 6) --splits;                     // >= 6 units (288 of K) per split
+    if (ws_bytes > 0 && p.tiles * 2 <= g_p3_target) {
+        splits = (int)min((long)8, (long)g_p3_target / p.tiles);
+        while (splits > 1 && units / splits < 4) --splits;                     // >= 4 units (192 of K) per split
         while (splits > 1 && (size_t)splits * M * Nn * sizeof(float) > ws_bytes) --splits;
     }
     p.units_per_split = (units + splits - 1) / splits;
@@ -388,6 +409,7 @@ PHNET_API int phnet_conv3p_splits(int64_t M, int32_t Ca, int32_t Nn, uint64_t ws
 
 PHNET_API int phnet_conv3p_tune(int32_t target_workgroups)
 {
+    if (target_workgroups == -1 || target_workgroups == -2) { g_p3_wide = target_workgroups == -2; return PHNET_OK; }   // -1: 64-column tiles only
     if (target_workgroups < 1) return PHNET_ERR_ARG;
     g_p3_target = target_workgroups;
     return PHNET_OK;
@@ -407,14 +429,13 @@ PHNET_API int phnet_conv3p_fwd(const float* x, const void* packed, const float* 
     const P3Plan p = p3_plan(M, Ca, Nn, workspace ? (size_t)ws_bytes : 0);
     P3Shape g{N, H, W, Ca, Nn, p.splits, p.units_per_split};
     float* dst = p.splits > 1 ? (float*)workspace : y;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv3p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P3_LDS);
-        attr_set = true;
-    }
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(conv3p_kernel, dim3((unsigned)p.tiles, 1, (unsigned)p.splits), dim3(P3_THREADS), P3_LDS, st,
-                       x, (const unsigned char*)packed, bias, addend, dst, g, relu, p.splits > 1 ? (float*)nullptr : stats);
+    if (p.fn == 2)
+        hipLaunchKernelGGL(conv3p_kernel<2>, dim3((unsigned)p.tiles, 1, (unsigned)p.splits), dim3(P3_THREADS), P3_LDS, st,
+                           x, (const unsigned char*)packed, bias, addend, dst, g, relu, p.splits > 1 ? (float*)nullptr : stats);
+    else
+        hipLaunchKernelGGL(conv3p_kernel<1>, dim3((unsigned)p.tiles, 1, (unsigned)p.splits), dim3(P3_THREADS), P3_LDS, st,
+                           x, (const unsigned char*)packed, bias, addend, dst, g, relu, p.splits > 1 ? (float*)nullptr : stats);
     if (p.splits > 1) {
         const long total4 = M * Nn / 4;
         hipLaunchKernelGGL(conv3p_reduce_kernel, dim3((unsigned)cdiv(total4, 256)), dim3(256), 0, st,

@@ -85,19 +85,21 @@ __device__ __forceinline__ void finalize_column_sums(const float* __restrict__ p
     const int c = blockIdx.x * FIN_CH + cl;
     double a = 0.0, b = 0.0;
     if (c < C) {
-        // four rows per trip, all eight loads issued before the first add: the loop is a chain of memory latencies otherwise
-        // (rows beyond nblk re-read row g and are weighted 0: branch-free)
-        for (int r = g; r < nblk; r += 4 * FIN_G) {
-            float v[4], w[4];
+        // sixteen rows per trip, all 32 loads issued before the first add: the loop is a chain of memory latencies otherwise, and
+        // the partial rows of a trunk layer (<= 2500) are then covered by one or two trips (rows beyond nblk re-read row g and are
+        // weighted 0: branch-free)
+        constexpr int U = 16;
+        for (int r = g; r < nblk; r += U * FIN_G) {
+            float v[U], w[U];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < U; ++u) {
                 const int rr = r + u * FIN_G;
                 const size_t o = (size_t)(rr < nblk ? rr : g) * 2 * C + c;
                 v[u] = partial[o];
                 w[u] = partial[o + C];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < U; ++u) {
                 const bool in = r + u * FIN_G < nblk;
                 a += in ? (double)v[u] : 0.0;
                 b += in ? (double)w[u] : 0.0;

@@ -15,6 +15,8 @@ SHAPES = [("layer1", 5, 80, 200, 64, 64), ("layer2", 5, 40, 100, 128, 128), ("la
 
 def main():
     torch.manual_seed(0)
+    if "--narrow" in sys.argv:
+        assert lib().phnet_conv3p_tune(-1) == 0                # 64-column workgroup tiles only
     if "--target" in sys.argv:
         assert lib().phnet_conv3p_tune(int(sys.argv[sys.argv.index("--target") + 1])) == 0
     for name, n, h, w, ci, co in SHAPES:
