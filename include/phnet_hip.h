@@ -99,25 +99,11 @@ int phnet_conv3p_splits(int64_t M, int32_t Ca, int32_t Nn, uint64_t ws_bytes);
 int phnet_conv3p_fwd(const float* x, const void* packed, const float* bias, const float* addend, float* y, float* stats,
                      int32_t N, int32_t H, int32_t W, int32_t Ca, int32_t Nn, int32_t relu,
                      void* workspace, uint64_t ws_bytes, void* stream);
-int phnet_conv3p_tune(int32_t target_workgroups);   /* benchmarks only: workgroups a launch is topped up to by split-K */
 /* host-side query (no device work; bm/bn/splits/k_tile are HOST pointers): tile, split-K factor and K-tile depth the
  * two calls above use, i.e. the template arguments of the conv_igemm_kernel<BM, BN, DGRAD, BKT, UNI> they launch
  * (UNI = uniform-tap variant: 64x64 tile and A-side channel count % BKT == 0). */
 int phnet_conv2d_plan(int64_t M, int32_t Co, int32_t K, uint64_t ws_bytes, int32_t* bm, int32_t* bn, int32_t* splits,
                       int32_t* k_tile);
-/* tuning aid for benchmarks only (process-global): force tile/split-K of the next fwd/dgrad calls; bm=0 -> heuristic. */
-int phnet_tune_force_conv_tile(int32_t bm, int32_t bn, int32_t splits);
-int phnet_tune_force_k_tile(int32_t k_tile);   /* 0 = heuristic, else 16 | 32 | 64; -1 / -2: uniform-tap kernel variant off / on;
-                                                  -5 / -6: three-taps 3x3 stride-1 forward / dgrad kernel off / on */
-int phnet_tune_wgrad(int32_t allow_bm128, int32_t target_blocks);   /* wgrad tile / split-K policy; bits of the first argument:
-                                                                        1 = no few-rows Linear kernel, 3 = no three-taps 3x3 kernel,
-                                                                        4 = its 32-pixel steps; a NEGATIVE second argument sets the
-                                                                        three-taps kernel's workgroup target (default 256) */
-/* arithmetic of conv2d fwd / dgrad / wgrad (process-global): 0 = f32-input MFMA (default, what every published number
- * uses), 1 = split-bf16: operands split in registers into two bf16 terms, 3 bf16 MFMAs per product, f32 accumulation
- * (~2^-16 relative per product); 2 = exact three-term bf16 split, 6 bf16 MFMAs per product (dropped terms <= 2^-24:
- * the accuracy of mode 0). */
-int phnet_tune_mma(int32_t mode);
 uint64_t phnet_conv2d_wgrad_workspace(int32_t N, int32_t Hi, int32_t Wi, int32_t Ci, int32_t Co,
                                       int32_t R, int32_t S, int32_t stride, int32_t pad);
 /* dbias (optional, [Co]) = sum of dy over all pixels = the bias gradient, produced by the same launch. */
@@ -177,7 +163,7 @@ int phnet_bn_bwd_apply_sums(const float* dy, const float* x, const float* y, con
 /* ---- input pre-processing of a clip: libs/dataset/openlane/datasetOL.py:40-52 (crop top rows, optional
  * flip), transforms.py:150-156 (iaa.Resize = cv2 INTER_CUBIC on uint8), datasetOL.py:63-75,11-17 (ToTensor, Normalize, stack).
  * frames u8 [T][H0][W0][3] RGB on the device; out f32 NCHW [T][3][oh][ow] (layout 0) or NHWC4 [T][oh][ow][4] (layout 1);
- * out_u8 optional [T][oh][ow][3]; xi/xc [ow][4], yi/yc [oh][4]: clamped source indices (int32) and 11-bit taps (int16, sum 2048)
+ * out_u8 optional [T][oh][ow][3]; xi/xc [ow][4], yi/yc [oh][4]: clamped source indices (int32) and 11-bit taps (int16, each saturate_cast<short>(c * 2048): sum 2047..2049)
  * of the half-pixel a = -0.75 cubic kernel, built once per geometry by the caller; mean3 / std3 are HOST pointers. ---- */
 int phnet_preprocess_u8(const uint8_t* frames, float* out, uint8_t* out_u8,
                         const int32_t* xi, const int16_t* xc, const int32_t* yi, const int16_t* yc,

@@ -8,10 +8,13 @@ Restates the image half of the reference's per-frame pipeline (SURVEY.md 8(f) ra
   libs/dataset/openlane/datasetOL.py:11-17   multibatch_collate_fn: stack the frames of a clip
 
 **PARITY UNPINNED**: cv2 / imgaug are not installed in this image and the reference ships no image fixtures, so nothing
-executed from the reference can confirm this file.  The bicubic resampling follows OpenCV's published algorithm for 8-bit
-images (imgproc/resize.cpp: half-pixel centres, a = -0.75 cubic kernel, 11-bit fixed-point coefficients whose rounding
-error is folded into the largest tap, replicated borders, 22-bit rounding shift with saturation) as recalled from its
-source; an off-by-one-LSB difference against a real cv2 build cannot be excluded.
+executed from the reference can confirm this file.  The bicubic resampling restates OpenCV's published algorithm for 8-bit
+images (the 4.x sources, modules/imgproc/src/resize.cpp: the generic path of cv::resize - half-pixel centres with the
+source coordinate rounded to float before its floor, `fx = (float)((dx + 0.5) * scale - 0.5); sx = cvFloor(fx); fx -= sx`;
+interpolateCubic with A = -0.75; every tap stored on its own as saturate_cast<short>(c * 2048), no renormalisation;
+replicated borders; HResizeCubic in 32-bit integers, VResizeCubic with FixedPtCast<int, uchar, 22>: (v + 2^21) >> 22,
+saturated) as recalled from that source; the SIMD paths of a real cv2 build are documented to give the same integers, but
+an off-by-one-LSB difference against one cannot be excluded.
 Only tests/ may import this.
 """
 import numpy as np
@@ -32,20 +35,17 @@ def cubic_coeffs(fx: np.ndarray) -> np.ndarray:
 
 
 def fixed_coeffs(fx: np.ndarray) -> np.ndarray:
-    """[n,4] int16 coefficients summing exactly to 2048 (the rounding residue goes to the largest tap)."""
+    """[n,4] int16 coefficients: saturate_cast<short>(c * 2048) per tap (round half to even, as cvRound), NOT renormalised."""
     c = cubic_coeffs(fx)
-    q = np.rint(c * COEF_SCALE).astype(np.int32)
-    resid = COEF_SCALE - q.sum(axis=1)
-    big = np.argmax(q, axis=1)
-    q[np.arange(q.shape[0]), big] += resid
+    q = np.clip(np.rint(c * np.float32(COEF_SCALE)), -32768, 32767)
     return q.astype(np.int16)
 
 
 def axis_table(n_dst: int, n_src: int):
     """(idx [n_dst,4] int32 clamped source indices, coef [n_dst,4] int16)."""
     scale = np.float64(n_src) / n_dst
-    f = (np.arange(n_dst, dtype=np.float64) + 0.5) * scale - 0.5
-    s = np.floor(f)
+    f = ((np.arange(n_dst, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)     # (float)((dx + 0.5) * scale_x - 0.5)
+    s = np.floor(f)                                                                        # cvFloor of the FLOAT coordinate
     fx = (f - s).astype(np.float32)
     idx = np.clip(s.astype(np.int64)[:, None] + np.arange(-1, 3)[None, :], 0, n_src - 1).astype(np.int32)
     return idx, fixed_coeffs(fx)

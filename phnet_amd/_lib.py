@@ -9,6 +9,7 @@ import re
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("PHNET_LIB") or os.path.join(_HERE, "lib", "libphnet_hip.so")      # PHNET_LIB: kernel experiments only
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "phnet_hip.h")
+TUNING_HEADER = os.path.join(os.path.dirname(_HERE), "include", "phnet_hip_tuning.h")    # benchmark / A-B switches, not the boundary
 
 _CTYPES = {"int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "uint64_t": ctypes.c_uint64,
            "float": ctypes.c_float, "int": ctypes.c_int, "void": None}
@@ -18,8 +19,10 @@ ERRORS = {-1: "PHNET_ERR_ARG (bad shape / null pointer / unsupported size)",
           -3: "PHNET_ERR_LAUNCH (HIP launch error)"}
 
 
-def declared_functions(header: str = HEADER):
-    """[(name, restype, [argtypes])] for every prototype in the public header."""
+def declared_functions(header: str = None):
+    """[(name, restype, [argtypes])] for every prototype in the public header (+ the tuning header when none is named)."""
+    if header is None:
+        return declared_functions(HEADER) + declared_functions(TUNING_HEADER)
     text = open(header).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     out = []

@@ -34,7 +34,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for s, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {s}")
-    if procs or not os.path.exists(SO):
+    if procs or not os.path.exists(SO) or any(os.path.getmtime(o) > os.path.getmtime(SO) for o in objs):      # (an object another build left behind)
         subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO, *objs])
     return SO
 

@@ -19,13 +19,7 @@
 // Roofline: MFMA-bound (f32-input MFMA, 157.3 TF/s dense).  Algorithmic FLOPs = 2*M*N*K.
 #include <type_traits>
 #include "igemm.h"
-#ifndef PHNET_INTERLEAVE
-#define PHNET_INTERLEAVE 1
-#endif
-static constexpr bool g_interleave = PHNET_INTERLEAVE != 0;
-#ifdef PHNET_STAMPS              /* diagnostic build only: per-phase cycle stamps of the GEMM loop (tests/tools/stamps.py) */
-__device__ unsigned long long g_stamps[8];
-#endif
+static constexpr bool g_interleave = true;                   // MFMA / VALU interleave hints of the staged-split loops
 
 using namespace igemm;
 
@@ -204,11 +198,7 @@ __device__ __forceinline__ void igemm_tile(
     auto load_global = [&](int kt, f32x4 (&a_reg)[A_LOADS], f32x4 (&b_reg)[B_LOADS], f32x4 (&a_relu)[AMASK ? A_LOADS : 1], unsigned& mask) {
         mask = 0;
         if constexpr (BUF) {
-#ifdef PHNET_FAKE_NOLOAD             /* timing experiment only: every tile after the first ring is an out-of-range (zero-fill, no traffic) load */
-            const bool tile_ok = kt < k_begin + PF * BKT;
-#else
             const bool tile_ok = kt < k_end;                             // uniform: K and the split bounds are multiples of BKT
-#endif
             const int s_tap = ((ur * g.Wi + uq) * g.Ci + uc0) * 4;
 #pragma unroll
             for (int i = 0; i < A_LOADS; ++i) {
@@ -297,23 +287,15 @@ __device__ __forceinline__ void igemm_tile(
                 v.x = a_relu[i].x > 0.f ? v.x : 0.f; v.y = a_relu[i].y > 0.f ? v.y : 0.f;
                 v.z = a_relu[i].z > 0.f ? v.z : 0.f; v.w = a_relu[i].w > 0.f ? v.w : 0.f;
             }
-#ifdef PHNET_FAKE_NOAW
-            if (S3) { if (v.x == 12345.678f) store_split3<AP3::PLANE>(a3, (a_row + ROWS_PER_PASS * i) * AP3::PITCH + a_chunk * 8, v); } else
-#else
             if (S3) store_split3<AP3::PLANE>(a3, (a_row + ROWS_PER_PASS * i) * AP3::PITCH + a_chunk * 8, v);
             else
-#endif
             *reinterpret_cast<f32x4*>(a + (a_row + ROWS_PER_PASS * i) * A_PITCH + a_chunk * 4) = v;
         }
         if (!B_DGRAD) {
 #pragma unroll
             for (int i = 0; i < B_LOADS; ++i) {
                 const f32x4 v = BUF ? b_reg[i] : ((mask >> (16 + i)) & 1u ? b_reg[i] : zero);
-#ifdef PHNET_FAKE_NOBW
-                if (S3) { if (v.x == 12345.678f) store_split3<BP3C::PLANE>(b3, (a_row + ROWS_PER_PASS * i) * BP3C::PITCH + a_chunk * 8, v); }
-#else
                 if (S3) store_split3<BP3C::PLANE>(b3, (a_row + ROWS_PER_PASS * i) * BP3C::PITCH + a_chunk * 8, v);
-#endif
                 else *reinterpret_cast<f32x4*>(b + (a_row + ROWS_PER_PASS * i) * B_PITCH + a_chunk * 4) = v;
             }
         } else {
@@ -351,13 +333,7 @@ __device__ __forceinline__ void igemm_tile(
 #pragma unroll
             for (int ks = 0; ks < BKT / BK; ++ks) {
                 Frag3 a[FM], b[FN];
-#ifdef PHNET_FAKE_NOREAD
-                if (kt == k_begin)
-#endif
                 read_kcontig3<FM, AP3::PITCH, AP3::PLANE>(A3 + buf * AP3::BYTES + wm * AP3::PITCH, lane, ks, a);
-#ifdef PHNET_FAKE_NOREAD
-                if (kt == k_begin)
-#endif
                 if (!B_DGRAD) read_kcontig3<FN, BP3C::PITCH, BP3C::PLANE>(B3 + buf * B3_BYTES + wn * BP3C::PITCH, lane, ks, b);
                 else read_kstrided3<FN, BP3S::PITCH, BP3S::PLANE>(B3 + buf * B3_BYTES + wn * 2, lane, ks, b);
                 mma3_step<FM, FN>(a, b, acc);
@@ -387,26 +363,10 @@ __device__ __forceinline__ void igemm_tile(
         // one iteration: slot U was emptied an iteration ago and takes tile tt + PF; tile tt (in LDS) is multiplied; tile
         // tt + 1 moves from its slot to the other LDS buffer.  Straight-line code (no branch between the loads and their use:
         // hipcc answers a branch with s_waitcnt vmcnt(0), which would drain the whole ring every iteration).
-#ifdef PHNET_STAMPS
-        unsigned long long st_load = 0, st_mma = 0, st_fill = 0, st_bar = 0;
-#define PHNET_STAMP(var, t_prev) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
-                                      var += now_ - t_prev; t_prev = now_; __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define PHNET_STAMP(var, t_prev) do { } while (0)
-#endif
         auto iteration = [&](auto U, int tt) {
             constexpr int u = decltype(U)::value;
-#ifdef PHNET_STAMPS
-            __builtin_amdgcn_sched_barrier(0);
-            unsigned long long tprev = __builtin_amdgcn_s_memtime();
-#endif
             load_global(k_begin + (tt + PF) * BKT, a_set[u], b_set[u], r_set[u], mask_set[u]);
-            PHNET_STAMP(st_load, tprev);
             multiply_tile(buf, k_begin + tt * BKT);
-#ifdef PHNET_STAMPS
-            { float sink_; asm volatile("v_mov_b32 %0, %1" : "=v"(sink_) : "v"(acc[0][0][0])); asm volatile("" :: "v"(sink_)); }
-#endif
-            PHNET_STAMP(st_mma, tprev);
             // keep the LDS fill (and the wait for the global loads in front of it) BEHIND the MFMAs: left alone, the
             // scheduler hoists it above them - the operands are already in registers - and every wave then sits out its
             // full load latency before it issues a single MFMA
@@ -415,10 +375,6 @@ __device__ __forceinline__ void igemm_tile(
             if (PF == 1) __builtin_amdgcn_sched_barrier(0);
             constexpr int v = (u + 1) % PF;
             store_lds(buf ^ 1, a_set[v], b_set[v], r_set[v], mask_set[v]);
-#ifdef PHNET_STAMPS
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-            PHNET_STAMP(st_fill, tprev);
             if (PF > 1 && S3 && g_interleave) {
                 // one MFMA, then a handful of the next tile's split / address instructions, ...: the matrix pipe takes an MFMA
                 // every 32 cycles and blocks the vector issue for 8 of them
@@ -428,21 +384,12 @@ __device__ __forceinline__ void igemm_tile(
                     __builtin_amdgcn_sched_group_barrier(0x002, (14 + FM * FN - 1) / (FM * FN), 0);
                 }
             }
-#ifndef PHNET_FAKE_NOBAR
             __syncthreads();
-#endif
-            PHNET_STAMP(st_bar, tprev);
             buf ^= 1;
         };
         int t = 0;
         for (; t + PF <= ntiles; t += PF) unroll_iterations<PF>(iteration, t);
         if (PF > 1) tail_iterations<PF - 1>(iteration, t, ntiles);
-#ifdef PHNET_STAMPS
-        if (lane == 0) {
-            atomicAdd(&g_stamps[0], st_load); atomicAdd(&g_stamps[1], st_mma); atomicAdd(&g_stamps[2], st_fill);
-            atomicAdd(&g_stamps[3], st_bar); atomicAdd(&g_stamps[4], (unsigned long long)ntiles);
-        }
-#endif
     }
 
     // ---- per-channel statistics of the result (BatchNorm's batch statistics without a second pass over the tensor):
@@ -1626,14 +1573,6 @@ PHNET_API int phnet_tune_wgrad(int32_t allow_bm128, int32_t target_blocks)
     return PHNET_OK;
 }
 
-#ifdef PHNET_STAMPS
-PHNET_API int phnet_debug_stamps(unsigned long long* out, int reset)
-{
-    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 8) != hipSuccess) return PHNET_ERR_LAUNCH;
-    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)) != hipSuccess) return PHNET_ERR_LAUNCH; }
-    return PHNET_OK;
-}
-#endif
 
 // Tuning aid (process-global): arithmetic of the GEMM kernels.  0 = f32-input MFMA (default), 1 = split-bf16 (igemm.h).
 PHNET_API int phnet_tune_mma(int32_t mode)

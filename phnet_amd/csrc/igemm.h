@@ -177,12 +177,8 @@ __device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& hi, un
 template <int PLANE>
 __device__ __forceinline__ void store_split3(unsigned char* planes, int off, const f32x4& v) {
     unsigned h0, m0, l0, h1, m1, l1;
-#ifdef PHNET_FAKE_SPLIT            /* timing experiment only: what the loop costs without the split's vector instructions */
-    h0 = m0 = l0 = __builtin_bit_cast(unsigned, v.x); h1 = m1 = l1 = __builtin_bit_cast(unsigned, v.z);
-#else
     split3_pair(v.x, v.y, h0, m0, l0);
     split3_pair(v.z, v.w, h1, m1, l1);
-#endif
     *reinterpret_cast<u32x2*>(planes + off) = (u32x2){h0, h1};
     *reinterpret_cast<u32x2*>(planes + PLANE + off) = (u32x2){m0, m1};
     *reinterpret_cast<u32x2*>(planes + 2 * PLANE + off) = (u32x2){l0, l1};

@@ -6,7 +6,7 @@
 // which the reference runs per frame on CPU data-loader workers; at the inference rates of this implementation (1 500
 // frames/s) that is the next bottleneck.
 //
-// Arithmetic: OpenCV's 8-bit bicubic resize (half-pixel centres, a = -0.75, 11-bit fixed-point taps summing to 2048,
+// Arithmetic: OpenCV's 8-bit bicubic resize (half-pixel centres, a = -0.75, 11-bit fixed-point taps stored per tap without renormalisation,
 // replicated borders, rounding 22-bit shift, saturation) followed by x/255 and (x - mean)/std in f32.  The tap tables are
 // built on the host side of the C-ABI once per geometry and passed in (idx [n][4] int32, coef [n][4] int16 per axis).
 // HBM-bound: 16 source bytes x 3 channels per output pixel (L2-served re-reads), 12-16 bytes written.
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(NT) void preprocess_kernel(
 // frames u8 [T][H0][W0][3] RGB (device) -> out f32: layout 0 = NCHW [T][3][out_h][out_w] (the reference's tensor), layout 1 =
 // NHWC padded to 4 channels [T][out_h][out_w][4] (what the stem convolution of this implementation stages: skips the
 // NCHW -> NHWC4 pass).  The top crop_top rows are dropped, flip != 0 mirrors left-right before resampling.
-// xi/xc: [out_w][4] source columns (int32, clamped) and 11-bit taps (int16, sum 2048); yi/yc the same for rows of the CROPPED
+// xi/xc: [out_w][4] source columns (int32, clamped) and 11-bit taps (int16, each saturate_cast<short>(c * 2048): sum 2047..2049); yi/yc the same for rows of the CROPPED
 // image.  out_u8 (optional) [T][out_h][out_w][3]: the resized 8-bit image (what the reference's `img_rgb` holds, x255).
 PHNET_API int phnet_preprocess_u8(const uint8_t* frames, float* out, uint8_t* out_u8,
                                   const int32_t* xi, const int16_t* xc, const int32_t* yi, const int16_t* yc,

@@ -21,17 +21,20 @@ _COEF_BITS = 11
 
 
 def _axis_table(n_dst: int, n_src: int):
-    """Clamped source indices [n_dst,4] int32 and fixed-point cubic taps [n_dst,4] int16 of one axis."""
+    """Clamped source indices [n_dst,4] int32 and fixed-point cubic taps [n_dst,4] int16 of one axis, as OpenCV's published
+    imgproc/src/resize.cpp builds them for 8-bit INTER_CUBIC (the 4.x sources: cv::resize -> the generic path's coefficient
+    loop + interpolateCubic): `fx = (float)((dx + 0.5) * scale - 0.5); sx = cvFloor(fx); fx -= sx;` - the source coordinate
+    is ROUNDED TO FLOAT before its floor is taken and the fraction is a float subtraction - and every tap is stored as
+    `saturate_cast<short>(c * 2048)` on its own: the four taps are NOT renormalised to sum to 2048 (they sum to 2047..2049)."""
     a = np.float32(-0.75)
-    f = (np.arange(n_dst, dtype=np.float64) + 0.5) * (np.float64(n_src) / n_dst) - 0.5
+    f = ((np.arange(n_dst, dtype=np.float64) + 0.5) * (np.float64(n_src) / n_dst) - 0.5).astype(np.float32)
     s = np.floor(f)
     fx = (f - s).astype(np.float32)
     c0 = ((a * (fx + 1) - 5 * a) * (fx + 1) + 8 * a) * (fx + 1) - 4 * a
     c1 = ((a + 2) * fx - (a + 3)) * fx * fx + 1
     c2 = ((a + 2) * (1 - fx) - (a + 3)) * (1 - fx) * (1 - fx) + 1
     c3 = np.float32(1.0) - c0 - c1 - c2
-    q = np.rint(np.stack([c0, c1, c2, c3], axis=1).astype(np.float32) * (1 << _COEF_BITS)).astype(np.int32)
-    q[np.arange(n_dst), np.argmax(q, axis=1)] += (1 << _COEF_BITS) - q.sum(axis=1)      # taps sum to 2048 exactly
+    q = np.clip(np.rint(np.stack([c0, c1, c2, c3], axis=1).astype(np.float32) * np.float32(1 << _COEF_BITS)), -32768, 32767).astype(np.int32)
     idx = np.clip(s.astype(np.int64)[:, None] + np.arange(-1, 3)[None, :], 0, n_src - 1).astype(np.int32)
     return idx, q.astype(np.int16)
 

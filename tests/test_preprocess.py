@@ -12,7 +12,14 @@ MEAN, STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
 
 def test_oracle_taps_sum_to_one_and_identity_resize_is_exact():
     idx, coef = P.axis_table(37, 91)
-    assert (coef.astype(np.int32).sum(1) == 2048).all() and idx.min() == 0 and idx.max() == 90
+    sums = coef.astype(np.int32).sum(1)                    # each tap is saturate_cast<short>(c * 2048) on its own: no renormalisation
+    assert sums.min() >= 2047 and sums.max() <= 2049 and idx.min() == 0 and idx.max() == 90
+    # the source coordinate is rounded to float BEFORE its floor (OpenCV: fx = (float)((dx + 0.5) * scale - 0.5); sx = cvFloor(fx))
+    f32 = ((np.arange(37, dtype=np.float64) + 0.5) * (91 / 37) - 0.5).astype(np.float32)
+    assert np.array_equal(idx[:, 1], np.clip(np.floor(f32).astype(np.int64), 0, 90))
+    from phnet_amd.libs.dataset.openlane.preprocess import _axis_table
+    hidx, hcoef = _axis_table(37, 91)                        # the host-side table builder of the product restates the same rule
+    assert np.array_equal(hidx, idx) and np.array_equal(hcoef, coef)
     r = np.random.default_rng(0)
     img = r.integers(0, 256, (23, 31, 3), dtype=np.uint8)
     assert np.array_equal(P.resize_cubic_u8(img, 23, 31), img)                      # fx = 0: taps (0, 2048, 0, 0)
