@@ -108,6 +108,9 @@ def parse():
     ap.add_argument("--collectives", default="rccl-streams", choices=["rccl-streams", "torch"],
                     help="N > 1, nccl backend: rccl-streams (default) = raw ncclAllReduce calls on our own streams, capturable "
                          "(phnet_amd/rccl.py); torch = torch.distributed Work objects, eager step only")
+    ap.add_argument("--small-allreduce", default=os.environ.get("PHNET_SMALL_ALLREDUCE", "rccl"), choices=["rccl", "ipc"],
+                    help="N > 1: how the SyncBatchNorm statistic exchanges (<= 8 KB, 72 per step) travel: rccl (default) = stock RCCL "
+                         "all-reduces on the compute stream; ipc = one launch per rank over hipIpc-mapped peer buffers (phnet_amd/ipc.py)")
     ap.add_argument("--tune-k-tile", type=int, default=None, help="tuning aid: phnet_tune_force_k_tile code (-5 = generic 3x3 forward / dgrad kernel)")
     ap.add_argument("--wgrad-flags", type=int, default=None, help="tuning aid: hip_ops.tune_wgrad flags (8 = generic 3x3 weight-gradient kernel)")
     ap.add_argument("--force-dp", action="store_true",
@@ -308,6 +311,9 @@ def main():
         if args.backend == "nccl" and args.collectives == "rccl-streams":
             from phnet_amd import rccl
             rccl.install()                           # two dedicated communicators, before anything is captured (phnet_amd/rccl.py)
+        if args.small_allreduce == "ipc" and world > 1:
+            from phnet_amd import ipc
+            ipc.install()                            # exchange buffers mapped by every peer, before anything is captured
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())

@@ -122,6 +122,21 @@ int phnet_linear_bwd(const float* dy, const float* x, const float* w, const floa
 int phnet_nchw3_to_nhwc4(const float* x, float* y, int32_t N, int32_t H, int32_t W, void* stream);
 int phnet_pad_channels(const float* src, float* dst, int64_t rows, int32_t cs, int32_t cd, void* stream);
 
+/* ---- one-shot all-reduce of small messages over peer-mapped buffers (csrc/ipc_allreduce.hip): the SyncBatchNorm statistic
+ * exchanges of trainOL.py:141 (<= 8 KB, 72 per step, on the critical path).  Each rank allocates an exchange buffer
+ * (phnet_ipc_alloc, phnet_ipc_buffer_bytes), hands its 64-byte handle to the peers over any host channel, maps theirs
+ * (phnet_ipc_open_handle) and passes the table of mapped pointers (a DEVICE array, entry `rank` = the local buffer) to
+ * phnet_oneshot_allreduce: in place, SUM, contributions added in rank order (bit-identical on every rank), one launch on
+ * `stream`, capturable.  ctrl: DEVICE {uint32 sequence, uint32 error}, sequence initialised to 1 on every rank. */
+uint64_t phnet_ipc_buffer_bytes(int32_t world, uint64_t max_bytes);
+int phnet_ipc_alloc(uint64_t bytes, void** ptr);
+int phnet_ipc_free(void* ptr);
+int phnet_ipc_get_handle(void* ptr, void* handle64);
+int phnet_ipc_open_handle(const void* handle64, void** ptr);
+int phnet_ipc_close_handle(void* ptr);
+int phnet_oneshot_allreduce(void* data, int32_t count, int32_t dtype, const void* peers, int32_t rank, int32_t world,
+                            int32_t cap, void* ctrl, void* stream);
+
 /* ---- BatchNorm2d / ReLU / residual: replaces F.batch_norm + relu + add (libs/models/resnet.py:79-95, 293-297) ---- */
 uint64_t phnet_channel_partials_size(int64_t M, int32_t C);   /* floats needed in `partial` */
 int phnet_bn_fwd_stats(const float* x, int64_t M, int32_t C, float eps, float momentum,

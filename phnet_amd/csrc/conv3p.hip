@@ -290,40 +290,58 @@ __global__ __launch_bounds__(P3_THREADS, FN == 1 ? 3 : 2) void conv3p_kernel(
 
 // out[i] = sum_z part[z][i] (+bias) (+addend) (relu); optionally the BatchNorm statistics rows of the result (conv.hip's
 // splitk_reduce_kernel, restated here so that this translation unit stands alone)
+constexpr int P3_RCH = 4;        // 1024-element chunks per workgroup of the statistics-producing reduce: 4x fewer partial rows to finalize
+
+__device__ __forceinline__ f32x4 conv3p_reduce_one(const float* __restrict__ part, float* __restrict__ out, const float* __restrict__ bias,
+                                                   const float* __restrict__ addend, long i, long total4, int ncols, int splits, int relu)
+{
+    const f32x4* p = reinterpret_cast<const f32x4*>(part) + i;
+    f32x4 v[8];
+#pragma unroll
+    for (int z = 0; z < 8; ++z) v[z] = p[(long)min(z, splits - 1) * total4];
+    f32x4 s = v[0];
+#pragma unroll
+    for (int z = 1; z < 8; ++z)
+        if (z < splits) s += v[z];
+    for (int z = 8; z < splits; ++z) s += p[(long)z * total4];
+    if (bias) s += *reinterpret_cast<const f32x4*>(bias + (int)((i * 4) % ncols));
+    if (addend) s += reinterpret_cast<const f32x4*>(addend)[i];
+    if (relu) { s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f); }
+    reinterpret_cast<f32x4*>(out)[i] = s;
+    return s;
+}
+
 __global__ __launch_bounds__(256) void conv3p_reduce_kernel(const float* __restrict__ part, float* __restrict__ out,
                                                             const float* __restrict__ bias, const float* __restrict__ addend,
                                                             long total4, int ncols, int splits, int relu, float* __restrict__ stats)
 {
     __shared__ f32x4 red_s[2][256];
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool ok = i < total4;
-    f32x4 s{0.f, 0.f, 0.f, 0.f};
-    if (ok) {
-        const f32x4* p = reinterpret_cast<const f32x4*>(part) + i;
-        f32x4 v[8];
-#pragma unroll
-        for (int z = 0; z < 8; ++z) v[z] = p[(long)min(z, splits - 1) * total4];
-        s = v[0];
-#pragma unroll
-        for (int z = 1; z < 8; ++z)
-            if (z < splits) s += v[z];
-        for (int z = 8; z < splits; ++z) s += p[(long)z * total4];
-        if (bias) s += *reinterpret_cast<const f32x4*>(bias + (int)((i * 4) % ncols));
-        if (addend) s += reinterpret_cast<const f32x4*>(addend)[i];
-        if (relu) { s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f); }
-        reinterpret_cast<f32x4*>(out)[i] = s;
+    if (stats == nullptr) {                                 // (uniform: every thread of the grid takes the same side)
+        const long i = (long)blockIdx.x * 256 + threadIdx.x;
+        if (i < total4) conv3p_reduce_one(part, out, bias, addend, i, total4, ncols, splits, relu);
+        return;
     }
-    if (stats == nullptr) return;                           // (uniform: every thread of the grid takes the same side)
-    red_s[0][threadIdx.x] = s;
-    red_s[1][threadIdx.x] = s * s;
+    // with statistics: P3_RCH chunks of 256 float4 per workgroup; a thread's column (4 i mod ncols) is the same in every chunk
+    // because 1024 is a multiple of ncols (a power of two <= 1024)
+    f32x4 a{0.f, 0.f, 0.f, 0.f}, b{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < P3_RCH; ++c) {
+        const long i = ((long)blockIdx.x * P3_RCH + c) * 256 + threadIdx.x;
+        if (i < total4) {
+            const f32x4 s = conv3p_reduce_one(part, out, bias, addend, i, total4, ncols, splits, relu);
+            a += s; b += s * s;
+        }
+    }
+    red_s[0][threadIdx.x] = a;
+    red_s[1][threadIdx.x] = b;
     __syncthreads();
-    const int c4 = ncols >> 2;                              // float4 columns; rows per workgroup = 256 / c4
+    const int c4 = ncols >> 2;                              // float4 columns; rows per chunk = 256 / c4
     if ((int)threadIdx.x < c4) {
-        f32x4 a = red_s[0][threadIdx.x], b = red_s[1][threadIdx.x];
-        for (int r = c4; r < 256; r += c4) { a += red_s[0][r + threadIdx.x]; b += red_s[1][r + threadIdx.x]; }
+        f32x4 sa = red_s[0][threadIdx.x], sb = red_s[1][threadIdx.x];
+        for (int r = c4; r < 256; r += c4) { sa += red_s[0][r + threadIdx.x]; sb += red_s[1][r + threadIdx.x]; }
         float* q = stats + (size_t)blockIdx.x * 2 * ncols + threadIdx.x * 4;
-        *reinterpret_cast<f32x4*>(q) = a;
-        *reinterpret_cast<f32x4*>(q + ncols) = b;
+        *reinterpret_cast<f32x4*>(q) = sa;
+        *reinterpret_cast<f32x4*>(q + ncols) = sb;
     }
 }
 
@@ -398,7 +416,7 @@ PHNET_API uint64_t phnet_conv3p_stats_blocks(int64_t M, int32_t Ca, int32_t Nn, 
 {
     if (!p3_applies((long)M, Ca, Nn)) return 0;
     const P3Plan p = p3_plan((long)M, Ca, Nn, (size_t)ws_bytes);
-    return (uint64_t)(p.splits > 1 ? cdiv((long)M * Nn / 4, 256) : cdiv((long)M, P3_BM) * (P3_BM / 64));
+    return (uint64_t)(p.splits > 1 ? cdiv((long)M * Nn / 4, 256 * P3_RCH) : cdiv((long)M, P3_BM) * (P3_BM / 64));
 }
 
 PHNET_API int phnet_conv3p_splits(int64_t M, int32_t Ca, int32_t Nn, uint64_t ws_bytes)
@@ -438,7 +456,7 @@ PHNET_API int phnet_conv3p_fwd(const float* x, const void* packed, const float* 
                            x, (const unsigned char*)packed, bias, addend, dst, g, relu, p.splits > 1 ? (float*)nullptr : stats);
     if (p.splits > 1) {
         const long total4 = M * Nn / 4;
-        hipLaunchKernelGGL(conv3p_reduce_kernel, dim3((unsigned)cdiv(total4, 256)), dim3(256), 0, st,
+        hipLaunchKernelGGL(conv3p_reduce_kernel, dim3((unsigned)cdiv(total4, stats ? 256 * P3_RCH : 256)), dim3(256), 0, st,
                            (const float*)workspace, y, bias, addend, total4, Nn, p.splits, relu, stats);
     }
     return phnet_launch_status();

@@ -85,10 +85,10 @@ __device__ __forceinline__ void finalize_column_sums(const float* __restrict__ p
     const int c = blockIdx.x * FIN_CH + cl;
     double a = 0.0, b = 0.0;
     if (c < C) {
-        // sixteen rows per trip, all 32 loads issued before the first add: the loop is a chain of memory latencies otherwise, and
+        // eight rows per trip, all 16 loads issued before the first add: the loop is a chain of memory latencies otherwise, and
         // the partial rows of a trunk layer (<= 2500) are then covered by one or two trips (rows beyond nblk re-read row g and are
         // weighted 0: branch-free)
-        constexpr int U = 16;
+        constexpr int U = 8;
         for (int r = g; r < nblk; r += U * FIN_G) {
             float v[U], w[U];
 #pragma unroll

@@ -87,6 +87,12 @@ def _direct(t: torch.Tensor, group=None):
 def allreduce_sum_(t: torch.Tensor, group=None) -> torch.Tensor:
     """In-place SUM over the ranks (blocking for the STREAM, not the host)."""
     if active(group):
+        if group is None and t.is_cuda:
+            from . import ipc
+            one = ipc.installed()                    # small messages over peer-mapped buffers, when selected (phnet_amd/ipc.py)
+            if one is not None and one.applies(t):
+                run_collective(lambda: one.all_reduce_(t))
+                return t
         tr = _direct(t, group)
         if tr is not None:
             run_collective(lambda: tr.all_reduce_(t))

@@ -25,7 +25,15 @@ def _worker(rank, world, port, backend, fn, ret, env):
         torch.cuda.set_device(0)
     dist.init_process_group(backend=backend, init_method="env://")
     try:
+        if os.environ.get("PHNET_SMALL_ALLREDUCE") == "ipc":
+            from phnet_amd import ipc
+            ipc.install()                                     # SyncBatchNorm exchanges over peer-mapped buffers (phnet_amd/ipc.py)
         ret[rank] = fn(rank, world)
+        if os.environ.get("PHNET_SMALL_ALLREDUCE") == "ipc":
+            from phnet_amd import ipc
+            ret[rank] = dict(ret[rank], ipc_calls=ipc.installed().calls, ipc_error=ipc.installed().error())
+            dist.barrier()
+            ipc.uninstall()
     finally:
         dist.destroy_process_group()
 
@@ -306,3 +314,45 @@ def gpu_rccl_inside_capture(rank, world):
         return {"captured": False, "error": f"{type(e).__name__}: {str(e)[:300]}"}
     finally:
         rccl.uninstall()
+
+
+def gpu_oneshot_allreduce_two_processes(rank, world):
+    """Two processes on the one card of the box (gloo carries the 64-byte handles): each maps the other's exchange buffer and
+    reduces float64 / float32 messages of the SyncBatchNorm sizes with one launch per rank - eagerly, repeatedly (sequence
+    numbers, both slots), and from a captured hipGraph replayed three times; through phnet_amd.parallel.allreduce_sum_ as the
+    SyncBatchNorm path calls it.  (Functional: on one card the peers' stores do not cross xGMI.)"""
+    from phnet_amd import ipc, parallel
+    one = ipc.install(max_bytes=16384)
+    out = {"world": one.world}
+    errs = []
+    for n, dt in ((1025, torch.float64), (1024, torch.float32), (129, torch.float64), (1, torch.float32), (2048, torch.float64)):
+        for rep in range(3):
+            gen = torch.Generator().manual_seed(100 * n + rep)
+            full = torch.randn(world, n, generator=gen, dtype=torch.float64)
+            mine = full[rank].to(dt).cuda()
+            parallel.allreduce_sum_(mine)
+            want = full.to(dt)[0].clone()
+            for r in range(1, world):
+                want = want + full.to(dt)[r]                  # rank order
+            errs.append(float((mine.cpu() - want).abs().max()))
+    out["eager_max_err"] = max(errs)
+    out["calls_eager"] = one.calls
+    # captured: the sequence number advances on the device, so every replay is a fresh exchange
+    x = torch.full((257,), float(rank + 1), dtype=torch.float64, device="cuda")
+    side = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+        x.mul_(2.0)
+        parallel.allreduce_sum_(x)
+    vals = []
+    for _ in range(3):
+        g.replay()
+        torch.cuda.synchronize()
+        vals.append(float(x[0]))
+    out["replays"] = vals
+    big = torch.ones(1 << 16, device="cuda")                  # above max_bytes: not taken by the one-shot path
+    out["big_applies"] = one.applies(big)
+    out["error_flag"] = one.error()
+    dist.barrier()
+    ipc.uninstall()
+    return out

@@ -17,8 +17,11 @@ def _need_gpu():
         pytest.skip("needs a GPU")
 
 
-def test_two_rank_syncbn_step_equals_reference_pair_fixture():
-    """BASELINE.json configs[2] semantics on two REAL ranks (one clip each): SyncBatchNorm statistics over both ranks
+@pytest.mark.parametrize("small", ["process-group", "ipc"])
+def test_two_rank_syncbn_step_equals_reference_pair_fixture(small):
+    """(small = "ipc": the 40 SyncBatchNorm exchanges go through the one-shot all-reduce over peer-mapped buffers,
+    phnet_amd/ipc.py, instead of the process group - same fixture, same bounds.)
+    BASELINE.json configs[2] semantics on two REAL ranks (one clip each): SyncBatchNorm statistics over both ranks
     (device-resident count, one small all-reduce per layer and direction), 4 gradient buckets issued in backward order.
     Against tests/golden/tiny_pair_syncbn_r18_64x160.npz (produced by the reference's own modules run over both clips):
     summed loss, per-frame losses, matched indices (exact), BatchNorm running statistics, per-parameter norms of the
@@ -27,7 +30,9 @@ def test_two_rank_syncbn_step_equals_reference_pair_fixture():
     from tests import dp_workers as W
     gold = dict(np.load(os.path.join(GOLD, "tiny_pair_syncbn_r18_64x160.npz")))
     names = json.load(open(os.path.join(GOLD, "grad_names_resnet18.json")))
-    res = W.run(W.gpu_two_rank_step_vs_pair_fixture, world=2, backend="gloo")
+    res = W.run(W.gpu_two_rank_step_vs_pair_fixture, world=2, backend="gloo", env={"PHNET_SMALL_ALLREDUCE": "ipc"} if small == "ipc" else None)
+    if small == "ipc":
+        assert all(r["ipc_calls"] == 40 and not r["ipc_error"] for r in res), [(r["ipc_calls"], r["ipc_error"]) for r in res]
     total = sum(r["loss"] for r in res)
     assert abs(total - gold["pair_loss"]) <= 1e-3 * abs(gold["pair_loss"]), (total, gold["pair_loss"])
     for b, r in enumerate(res):
@@ -113,3 +118,18 @@ def test_rccl_collective_inside_a_hipgraph_capture():
     (r,) = W.run(W.gpu_rccl_inside_capture, world=1, backend="nccl", env={"PHNET_FORCE_COLLECTIVES": "1"})
     assert r["captured"] and r["refused"], r
     assert r["small"] == 7.0 and r["big"] == 13.0 and r["big_last"] == 13.0 and r["calls"] == 3 and r["eager"] == 1.0, r
+
+
+def test_one_shot_all_reduce_over_peer_mapped_buffers():
+    """csrc/ipc_allreduce.hip + phnet_amd/ipc.py: the SyncBatchNorm-sized all-reduces as ONE launch per rank over hipIpc-mapped
+    exchange buffers (8-byte {data, sequence} granules, contributions added in rank order), two processes on the one card:
+    exact sums for float64 / float32 messages of 1 .. 2048 elements over repeated calls, and from a captured graph replayed three
+    times (x -> 2x summed over the ranks, each replay a fresh exchange: 6, 24, 96 ... for ranks holding 1 and 2)."""
+    _need_gpu()
+    from tests import dp_workers as W
+    res = W.run(W.gpu_oneshot_allreduce_two_processes, world=2, backend="gloo", env={"PHNET_FORCE_COLLECTIVES": "0"})
+    for r in res:
+        assert r["world"] == 2 and not r["error_flag"] and not r["big_applies"], r
+        assert r["eager_max_err"] == 0.0 and r["calls_eager"] == 15, r
+        # replay k: every rank doubles its vector, then both hold the sum: 2*(1+2) = 6 -> 2*(6+6) = 24 -> 96
+        assert r["replays"] == [6.0, 24.0, 96.0], r
