@@ -254,6 +254,15 @@ int phnet_frame_loss(const float* const* pred, const float* const* gate, const f
                      float liou_half_width, float liou_img_h, float liou_img_w,
                      float* loss, float* const* dpred, float* dgate,
                      int64_t* rows_by_col, int64_t* rows_sorted, float* focal, float* scalars, void* stream);
+/* the reference's other two criteria, fused the same way (csrc/loss_variants.hip; two launches per frame):
+ * variant 1 = libs/utils/loss4OL.py:88-232 (per-pair terms summed by position, placed on the last stage's anchors),
+ * variant 2 = libs/utils/loss4OLV2.py:12-186 (one-to-many assignment, up to 16 pairs per branch and stage).
+ * pair_rows / pair_cols [6][16] int64 (-1 padded), rows_sorted [6][L] int64 (variant 1), scratch 6*N + 192 floats. */
+int phnet_frame_loss_variant(int32_t variant, const float* const* pred, const float* const* gate, const float* tgt,
+                             int32_t N, int32_t L, int32_t S, float img_w, float img_h,
+                             float cls_w, float reg_w, float iou_w,
+                             float* loss, float* const* dpred, float* dgate,
+                             int64_t* pair_rows, int64_t* pair_cols, int64_t* rows_sorted, float* scratch, void* stream);
 
 /* ---- lane prior update: replaces the tanh/tan/repeat/cat chain of forward_first/second (Router4OL.py:328-345) and its
  * backward.  priors [N][6+S]; head [N][HW] = (cls 2 | reg 4 | offsets S | zero pad); ys [S] = prior_ys. ---- */

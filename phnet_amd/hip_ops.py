@@ -645,6 +645,32 @@ def lane_assign_one2many(pred, tgt, img_w: int, img_h: int):
     return rows, cols, cnt
 
 
+def frame_loss_variant(variant: int, preds, gates, tgt, img_w, img_h, cls_w, reg_w, iou_w):
+    """The loss4OL (variant 1) / loss4OLV2 (variant 2) criterion of one frame in two launches (csrc/loss_variants.hip).
+    preds: 6 x [N,6+S], gates: 3 x [N], tgt [L,6+S] -> (loss [1], dpred [6,N,6+S], dgate [3,N], pair_rows [6,16] i64,
+    pair_cols [6,16] i64, rows_sorted [6,L] i64)."""
+    import ctypes
+    for t in list(preds) + list(gates) + [tgt]:
+        _req(t, name="loss input")
+    n, w = preds[0].shape
+    L = tgt.shape[0]
+    dev = tgt.device
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    dpred = torch.empty((6, n, w), dtype=torch.float32, device=dev)
+    dgate = torch.empty((3, n), dtype=torch.float32, device=dev)
+    prow = torch.empty((6, 16), dtype=torch.int64, device=dev)
+    pcol = torch.empty((6, 16), dtype=torch.int64, device=dev)
+    srt = torch.full((6, L), -1, dtype=torch.int64, device=dev)
+    scratch = torch.empty(6 * n + 192, dtype=torch.float32, device=dev)
+    P = (ctypes.c_void_p * 6)(*[t.data_ptr() for t in preds])
+    G = (ctypes.c_void_p * 3)(*[t.data_ptr() for t in gates])
+    D = (ctypes.c_void_p * 6)(*[dpred[i].data_ptr() for i in range(6)])
+    check(lib().phnet_frame_loss_variant(int(variant), P, G, _ptr(tgt), n, L, w - 6, float(img_w), float(img_h), float(cls_w), float(reg_w),
+                                         float(iou_w), _ptr(loss), D, _ptr(dgate), _ptr(prow), _ptr(pcol), _ptr(srt), _ptr(scratch),
+                                         _stream()), "phnet_frame_loss_variant")
+    return loss, dpred, dgate, prow, pcol, srt
+
+
 def frame_loss(preds, gates, tgt, img_w, img_h, cls_w, reg_w, iou_w, liou_hw, liou_h, liou_w):
     """preds: 6 x [N,6+S] (branch A stages 0..2, branch B stages 0..2), gates: 3 x [N], tgt [L,6+S].
     Returns (loss [1], dpred [6,N,6+S], dgate [3,N], rows_by_col [6,L] i64, rows_sorted [6,L] i64)."""

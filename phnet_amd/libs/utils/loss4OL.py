@@ -5,9 +5,11 @@ PAIR (smooth-L1 mean over the four start / angle / length values, 1 - line IoU w
 of pairs), are summed over the stages BY POSITION in the row-sorted pair list and land on the anchors matched at the LAST stage; the
 branch balance (median shift, gate-weighted sum) then acts on that whole per-anchor loss vector.
 
-Sync-free like the V3 criterion: the assignment is the HIP kernel `phnet_lane_assign` (exact matching, no scipy, no device->host
-copy), label rows are carried with a validity mask, matched anchors come back as fixed-size vectors padded with -1; the loss
-arithmetic is device tensor ops under autograd.  Only the default `stageMode=False` path of the reference is built."""
+Sync-free like the V3 criterion and fused like it: `phnet_frame_loss_variant` (csrc/loss_variants.hip) computes the assignment
+(exact matching, no scipy, no device->host copy), every loss term and every input gradient of a frame in two launches; label
+rows are carried with a validity mask, matched anchors come back as fixed-size vectors padded with -1.  `fused = False` spells
+the same arithmetic in device tensor ops (the kernels' cross-check).  Only the default `stageMode=False` path of the reference
+is built."""
 import torch
 import torch.nn.functional as F
 
@@ -21,6 +23,33 @@ def line_iou_rows(pred_px, tgt_px, img_w: float, radius: float = 15.0):
     ovr = (torch.min(pred_px + radius, tgt_px + radius) - torch.max(pred_px - radius, tgt_px - radius)) * ok
     uni = (torch.max(pred_px + radius, tgt_px + radius) - torch.min(pred_px - radius, tgt_px - radius)) * ok
     return ovr.sum(-1) / (uni.sum(-1) + 1e-9)
+
+
+class _FusedVariantLoss(torch.autograd.Function):
+    """(6 predictions, 3 gates) -> frame loss of criterion variant 1 / 2: phnet_frame_loss_variant computes the value and every
+    input gradient in two launches (csrc/loss_variants.hip)."""
+
+    @staticmethod
+    def forward(ctx, crit, variant, tgt, *tensors):
+        preds = [t.reshape(-1, t.shape[-1]).contiguous() for t in tensors[:6]]
+        gates = [t.reshape(-1).contiguous() for t in tensors[6:]]
+        loss, dpred, dgate, prow, pcol, srt = K.frame_loss_variant(variant, preds, gates, tgt.contiguous(), crit.img_w, crit.img_h,
+                                                                   crit.cls_weight, crit.reg_weight, crit.iou_weight)
+        ctx.save_for_backward(dpred, dgate)
+        ctx.pshape, ctx.gshape = tensors[0].shape, tensors[6].shape
+        ctx.mark_non_differentiable(prow, pcol, srt)
+        return loss.view(()), prow, pcol, srt
+
+    @staticmethod
+    def backward(ctx, gloss, *_):
+        dpred, dgate = ctx.saved_tensors
+        dp, dg = dpred * gloss, dgate * gloss
+        return (None, None, None, *[dp[i].view(ctx.pshape) for i in range(6)], *[dg[i].view(ctx.gshape) for i in range(3)])
+
+
+def fusable(targets, fa, fb) -> bool:
+    return (targets.shape[0] == 1 and len(fa) == 3 and len(fb) == 3 and targets.shape[1] <= 4 and fa[0].shape[-2] <= 256
+            and fa[0].is_cuda)
 
 
 class Criterion4OL(_CriterionV3):
@@ -72,6 +101,15 @@ class Criterion4OL(_CriterionV3):
 
     def loss4OneStep(self, output, batch, diff=None, stageMode=False):
         assert diff is not None
+        targets = batch["lane_line"]
+        fa, fb = output["predictions_fir"], output["predictions_sec"]
+        if self.fused and not stageMode and fusable(targets, fa, fb):
+            loss, _, _, srt = _FusedVariantLoss.apply(self, 1, targets[0], *fa, *fb, *diff)
+            return [srt[3], srt[4], srt[5]], loss
+        return self.loss4OneStep_tensor_ops(output, batch, diff, stageMode)
+
+    def loss4OneStep_tensor_ops(self, output, batch, diff=None, stageMode=False):
+        """The same criterion in device tensor ops (~450 launches per frame; the cross-check of the fused kernels)."""
         targets = batch["lane_line"]
         ma, cls_a, reg_a, iou_a = self.line_loss_diff(output["predictions_fir"], targets, stageMode)
         mb, cls_b, reg_b, iou_b = self.line_loss_diff(output["predictions_sec"], targets, stageMode)

@@ -921,10 +921,12 @@ def _criterion_cases(g):
 
 
 @pytest.mark.parametrize("tag", ["v1", "v2"])
-def test_criterion_variants_vs_reference_fixture(tag):
+@pytest.mark.parametrize("fused", [True, False])
+def test_criterion_variants_vs_reference_fixture(tag, fused):
     """libs.utils.loss4OL (trainOLV2/V3.py) and libs.utils.loss4OLV2 (one-to-many assignment) on the device against what the
     reference's own classes produced on the same head outputs (tests/golden/make_goldens_criteria.py): matched anchors exact
-    (the one-to-many pairs in the reference's round order), loss 1e-5 relative, every input gradient 1e-4."""
+    (the one-to-many pairs in the reference's round order), loss 1e-5 relative, every input gradient 1e-4.  fused: the two-launch
+    kernels of csrc/loss_variants.hip (the default) / the same arithmetic spelled in device tensor ops."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from phnet_amd.config import make_cfg
@@ -935,6 +937,7 @@ def test_criterion_variants_vs_reference_fixture(tag):
     else:
         from phnet_amd.libs.utils.loss4OLV2 import Criterion4OL
     crit = Criterion4OL(cfg).cuda()
+    crit.fused = fused
     gold = _gold("criterion_variants_tiny.npz")
     for i, (fir, sec, gate, gt) in enumerate(_criterion_cases(g)):
         f = [torch.from_numpy(fir[s]).unsqueeze(0).cuda().requires_grad_() for s in range(3)]
@@ -953,6 +956,9 @@ def test_criterion_variants_vs_reference_fixture(tag):
         if tag == "v2":
             k = int((matched[-1] >= 0).sum())
             assert res[2].shape == (1, 16, 42) and k == int((gold["v2_matched"][i, 2] >= 0).sum())
+            rows = matched[-1]
+            want = s_[2].detach()[0][rows.clamp(min=0)] * (rows >= 0)[:, None]          # matched rows, ZERO where the pair list is padded
+            assert torch.equal(res[2][0], want)
 
 
 def test_training_step_with_the_loss4ol_criterion_equals_oracle_on_the_same_head_outputs():
