@@ -24,6 +24,9 @@ int phnet_tune_wgrad(int32_t allow_bm128, int32_t target_blocks);   /* wgrad til
 int phnet_tune_mma(int32_t mode);
 /* packed-weight 3x3 kernel: workgroups a launch is topped up to by split-K (default 512); -1 / -2: 128-column tiles off / on */
 int phnet_conv3p_tune(int32_t target_workgroups);
+/* routing gate's depth-wise stack: 1 = one wavefront per plane (csrc/gate_wave.hip, default where C = 64, P = 36), 0 = the generic
+ * one-workgroup-per-plane kernels (csrc/gate.hip) */
+int phnet_tune_gate_wave(int32_t on);
 
 #ifdef __cplusplus
 }

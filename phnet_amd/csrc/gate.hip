@@ -345,9 +345,19 @@ __global__ __launch_bounds__(256) void gate_filter_grad_reduce_kernel(const floa
     *dst = old + s;
 }
 
+int g_gate_wave = 1;            // wave-per-plane kernels (gate_wave.hip) where they apply; phnet_tune_gate_wave(0) = the generic ones
+
 bool gate_args_ok(int N, int C, int P) { return N >= 1 && C >= 1 && P >= 1 && (long)C * P <= (long)NT * EPT; }
 
 }  // namespace
+
+extern "C" int phnet_gate_wave_applies(int32_t C, int32_t P);
+extern "C" int phnet_gate_wave_fwd(const float* x, const float* const* params, float* out, float* saved, int32_t N, int32_t anchors, float eps,
+                                   void* stream);
+extern "C" int phnet_gate_wave_bwd(const float* gout, const float* x, const float* out, const float* const* params, const float* saved, float* const* grads,
+                                   int32_t N, int32_t anchors, float eps, int32_t accumulate, void* workspace, void* stream);
+
+PHNET_API int phnet_tune_gate_wave(int32_t on) { g_gate_wave = on != 0; return PHNET_OK; }
 
 PHNET_API uint64_t phnet_gate_stack_saved_floats(int32_t N, int32_t C, int32_t P) { return (uint64_t)12 * N * C * P + (uint64_t)18 * N; }
 PHNET_API uint64_t phnet_gate_stack_bwd_workspace(int32_t N, int32_t C, int32_t P) { return ((uint64_t)18 * N * C * P + (uint64_t)80 * N) * sizeof(float); }
@@ -362,6 +372,7 @@ PHNET_API int phnet_gate_stack_fwd(const float* x, const float* const* params, f
     if (!gate_args_ok(N, C, P) || anchors < 1 || N % anchors || !x || !params || !out) return PHNET_ERR_ARG;
     GateParams w;
     for (int i = 0; i < NPARAM; ++i) { w.p[i] = params[i]; if (!params[i]) return PHNET_ERR_ARG; }
+    if (g_gate_wave && phnet_gate_wave_applies(C, P)) return phnet_gate_wave_fwd(x, params, out, saved, N, anchors, eps, stream);
     const size_t CP = (size_t)C * P;
     float* stats = saved ? saved + (size_t)12 * N * CP : nullptr;
     hipLaunchKernelGGL(gate_stack_fwd_kernel, dim3(N), dim3(NT), 2 * CP * sizeof(float), (hipStream_t)stream,
@@ -383,6 +394,11 @@ PHNET_API int phnet_gate_stack_bwd(const float* gout, const float* x, const floa
     GateParams w; GateGrads dg;
     for (int i = 0; i < NPARAM; ++i) { w.p[i] = params[i]; dg.p[i] = grads[i]; if (!params[i] || !grads[i]) return PHNET_ERR_ARG; }
     hipStream_t st = (hipStream_t)stream;
+    if (g_gate_wave && phnet_gate_wave_applies(C, P)) {
+        // (the forward of the same switch position saved the four block inputs; partial-gradient layouts are shared with the generic kernel)
+        const int rc = phnet_gate_wave_bwd(gout, x, out, params, saved, grads, N, anchors, eps, accumulate, workspace, stream);
+        if (rc != PHNET_OK) return rc;
+    } else
     hipLaunchKernelGGL(gate_stack_bwd_kernel, dim3(N), dim3(NT), 2 * CP * sizeof(float), st,
                        gout, x, out, w, saved, saved + (size_t)12 * N * CP, dg, (float*)workspace, fpart, N, anchors, C, P, eps, accumulate);
     if (N != anchors)

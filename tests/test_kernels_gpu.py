@@ -24,11 +24,11 @@ def nhwc(t):   # NCHW cpu -> NHWC cuda
     return t.permute(0, 2, 3, 1).contiguous().cuda()
 
 
-def close(a, b, tol=2e-4):
+def close(a, b, tol=2e-4, what=""):
     a, b = a.detach().cpu().double(), b.detach().cpu().double()
     scale = max(1.0, float(b.abs().max()))
     err = float((a - b).abs().max())
-    assert err <= tol * scale, (err, scale)
+    assert err <= tol * scale, (what, err, scale)
 
 
 # ------------------------------------------------------------------------------------------------ NMS
@@ -1029,18 +1029,23 @@ def test_lane_decode_matches_oracle_decode(ops, seed, thr):
 
 
 # ------------------------------------------------------------------------------------------------ routing gate stack
-def _gate_reference(x, params, eps):
+def _gate_reference(x, params, eps, kink=None):
     """libs/models/Router.py:72-75 spelled in fp64 tensor ops: pre_norm, then 4 x relu(DWblock(s) + s) with
-    DWblock = dwconv3x3 -> LN([C,P]) -> ReLU -> dwconv3x3 -> LN([C,P]); x [B,N,C,P], per-anchor filters [N,1,3,3]."""
+    DWblock = dwconv3x3 -> LN([C,P]) -> ReLU -> dwconv3x3 -> LN([C,P]); x [B,N,C,P], per-anchor filters [N,1,3,3].
+    kink (optional list): receives, per ReLU, the smallest |pre-activation| of every plane [B,N]."""
     n, (c, p) = x.shape[1], x.shape[2:]
     s = F.layer_norm(x, (c, p), params[0], params[1], eps)
     for b in range(4):
         w1, b1, g1, e1, w2, b2, g2, e2 = params[2 + 8 * b: 10 + 8 * b]
         t = F.conv2d(s, w1, b1, padding=1, groups=n)
-        t = torch.relu(F.layer_norm(t, (c, p), g1, e1, eps))
-        t = F.conv2d(t, w2, b2, padding=1, groups=n)
-        t = F.layer_norm(t, (c, p), g2, e2, eps)
-        s = torch.relu(t + s)
+        t = F.layer_norm(t, (c, p), g1, e1, eps)
+        if kink is not None:
+            kink.append(t.detach().abs().amin(dim=(2, 3)))
+        t = F.conv2d(torch.relu(t), w2, b2, padding=1, groups=n)
+        t = F.layer_norm(t, (c, p), g2, e2, eps) + s
+        if kink is not None:
+            kink.append(t.detach().abs().amin(dim=(2, 3)))
+        s = torch.relu(t)
     return s
 
 
@@ -1064,8 +1069,16 @@ def test_gate_stack_fwd_bwd_vs_fp64_statement(ops, B, N, C, P):
     eps = 1e-5
     x = torch.randn(B, N, C, P, dtype=torch.float64)
     params = _gate_params(N, C, P, seed=N + C)
-    ref = _gate_reference(x, params, eps)
+    kink = []
+    ref = _gate_reference(x, params, eps, kink)
     gout = torch.randn_like(ref)
+    # A plane with a pre-activation within fp32 rounding of a ReLU kink has no well-defined fp32 gradient: whichever side an
+    # implementation's rounding lands on switches that element's whole gradient path (on the 5 x 240 case the fp64 statement
+    # holds pre-activations of 4e-8 and 1.2e-7; an LN output carries ~3e-7 of fp32 rounding).  Such planes (a few per thousand
+    # at this margin) get a zero upstream gradient, so the comparison is decided by arithmetic, not by the luck of a rounding.
+    at_kink = torch.stack(kink).amin(dim=0) < 3e-6                          # [B,N]
+    assert float(at_kink.double().mean()) < 0.05
+    gout[at_kink] = 0.0
     ref.backward(gout)
     xd = dev(x.float().reshape(B * N, C, P))
     pd = [dev(t.detach().float()) for t in params]
@@ -1087,14 +1100,14 @@ def test_gate_stack_fwd_bwd_vs_fp64_statement(ops, B, N, C, P):
         if is_conv_bias(i):
             assert float(p.grad.abs().max()) < 1e-9 and float(got.abs().max()) <= noise, (i, float(got.abs().max()), noise)
         else:
-            close(got.view(p.shape), p.grad, 5e-5)
+            close(got.view(p.shape), p.grad, 5e-5, f"parameter {i} (overwrite)")
     acc = [torch.ones_like(t) for t in pd]
     ops.gate_stack_bwd(gd, xd, out, pd, saved, acc, eps, True, anchors=N)
     for i, (got, p) in enumerate(zip(acc, params)):
         if is_conv_bias(i):
             assert float((got - 1.0).abs().max()) <= noise + 1e-6, i
         else:
-            close(got.view(p.shape) - 1.0, p.grad, 5e-5)
+            close(got.view(p.shape) - 1.0, p.grad, 5e-5, f"parameter {i} (accumulate)")
 
 
 def test_gate_stack_through_the_module_matches_reference_gate(ops):

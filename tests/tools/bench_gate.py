@@ -6,6 +6,9 @@ from phnet_amd import hip_ops as K
 from bench_conv import timeit
 
 def main():
+    from phnet_amd._lib import lib
+    if "--generic" in sys.argv:
+        assert lib().phnet_tune_gate_wave(0) == 0              # one workgroup per plane (csrc/gate.hip) instead of one wavefront
     B, N, C, P = 5, 240, 64, 36
     g = torch.Generator(device="cuda").manual_seed(0)
     rn = lambda *s, scale=1.0: torch.randn(*s, generator=g, device="cuda") * scale       # noqa: E731
