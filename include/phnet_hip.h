@@ -292,6 +292,7 @@ int phnet_gate_stack_bwd(const float* gout, const float* x, const float* out, co
 /* the wave-per-plane forms of the two calls above (csrc/gate_wave.hip; C = 64, P = 36: what the model runs) - phnet_gate_stack_fwd /
  * _bwd dispatch to them where phnet_gate_wave_applies; `saved` then holds only the four block inputs [4][N][C*P] */
 int phnet_gate_wave_applies(int32_t C, int32_t P);
+int phnet_gate_wave_partial_planes(int32_t N);
 int phnet_gate_wave_fwd(const float* x, const float* const* params, float* out, float* saved,
                         int32_t N, int32_t anchors, float eps, void* stream);
 int phnet_gate_wave_bwd(const float* gout, const float* x, const float* out, const float* const* params, const float* saved,

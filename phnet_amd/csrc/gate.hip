@@ -352,6 +352,7 @@ bool gate_args_ok(int N, int C, int P) { return N >= 1 && C >= 1 && P >= 1 && (l
 }  // namespace
 
 extern "C" int phnet_gate_wave_applies(int32_t C, int32_t P);
+extern "C" int phnet_gate_wave_partial_planes(int32_t N);
 extern "C" int phnet_gate_wave_fwd(const float* x, const float* const* params, float* out, float* saved, int32_t N, int32_t anchors, float eps,
                                    void* stream);
 extern "C" int phnet_gate_wave_bwd(const float* gout, const float* x, const float* out, const float* const* params, const float* saved, float* const* grads,
@@ -394,7 +395,9 @@ PHNET_API int phnet_gate_stack_bwd(const float* gout, const float* x, const floa
     GateParams w; GateGrads dg;
     for (int i = 0; i < NPARAM; ++i) { w.p[i] = params[i]; dg.p[i] = grads[i]; if (!params[i] || !grads[i]) return PHNET_ERR_ARG; }
     hipStream_t st = (hipStream_t)stream;
+    int part_planes = N;                                           // partial planes of the LayerNorm affine gradients the column reduce reads
     if (g_gate_wave && phnet_gate_wave_applies(C, P)) {
+        part_planes = phnet_gate_wave_partial_planes(N);
         // (the forward of the same switch position saved the four block inputs; partial-gradient layouts are shared with the generic kernel)
         const int rc = phnet_gate_wave_bwd(gout, x, out, params, saved, grads, N, anchors, eps, accumulate, workspace, stream);
         if (rc != PHNET_OK) return rc;
@@ -405,6 +408,6 @@ PHNET_API int phnet_gate_stack_bwd(const float* gout, const float* x, const floa
         hipLaunchKernelGGL(gate_filter_grad_reduce_kernel, dim3((anchors * 80 + 255) / 256), dim3(256), 0, st, fpart, dg, N, anchors,
                            accumulate);
     hipLaunchKernelGGL(gate_ln_grad_reduce_kernel, dim3((unsigned)ceil_div64(18L * CP, 64)), dim3(256), 0, st,
-                       (const float*)workspace, dg, N, (int)CP, accumulate);
+                       (const float*)workspace, dg, part_planes, (int)CP, accumulate);
     return phnet_launch_status();
 }

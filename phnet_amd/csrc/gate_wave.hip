@@ -9,7 +9,8 @@
 // p +/- 1 taps of the filter are the lane's own registers, the c +/- 1 taps come from the neighbour lanes by DPP wave shifts
 // (zero-filled at lanes 0 / 63 = the zero padding), the per-anchor filters are wave-uniform scalars.  No barrier, no LDS in
 // the forward.  The backward RECOMPUTES a block from its input (the only planes the training forward saves: 4 instead of
-// 12) and parks two planes in wave-private LDS; 8 planes per CU are in flight, a 1200-plane launch is a single round.
+// 12), parks one plane per wave in LDS and folds the LayerNorm affine partials of a workgroup's four planes before they leave
+// the CU; 8 planes per CU are in flight, a 1200-plane launch is a single round.
 // LayerNorm statistics: two-pass (mean, then the variance of the centred values), as gate.hip.
 #include "common.h"
 
@@ -43,14 +44,14 @@ __device__ __forceinline__ void store_row(float* __restrict__ dst, const float (
 }
 
 __device__ __forceinline__ void plane_stats(const float (&v)[GP], float eps, float& mu, float& rs) {
-    float s = 0.f;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};                            // four chains: a lone wave issues dependent adds at their latency
 #pragma unroll
-    for (int p = 0; p < GP; ++p) s += v[p];
-    mu = wave_sum(s) / (float)GCP;
-    float q = 0.f;
+    for (int p = 0; p < GP; ++p) s[p & 3] += v[p];
+    mu = wave_sum((s[0] + s[1]) + (s[2] + s[3])) * (1.0f / (float)GCP);
+    float q[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int p = 0; p < GP; ++p) { const float d = v[p] - mu; q += d * d; }
-    rs = 1.0f / sqrtf(wave_sum(q) / (float)GCP + eps);
+    for (int p = 0; p < GP; ++p) { const float d = v[p] - mu; q[p & 3] += d * d; }
+    rs = 1.0f / sqrtf(wave_sum((q[0] + q[1]) + (q[2] + q[3])) * (1.0f / (float)GCP) + eps);
 }
 
 // out[c][p] = bias + sum f[di][dj] * in[c + di - 1][p + dj - 1] (zero padding); flip: the 180-degree rotated filter (conv backward)
@@ -72,16 +73,16 @@ __device__ __forceinline__ void dwconv(const float (&in)[GP], const float* __res
     }
 }
 
-// x = relu?((x - mu) * rs * w + b (+ res))
-__device__ __forceinline__ void ln_apply(float (&x)[GP], float mu, float rs, const float* __restrict__ w, const float* __restrict__ b,
-                                         const float* res, bool relu) {
-    float wv[GP], bv[GP];
-    load_row(w, wv); load_row(b, bv);
+// x = relu?((x - mu) * rs * w + b (+ res)) on rows the caller loaded EARLY (a lone wave per SIMD has nothing to hide a load behind
+// except its own arithmetic: the affine rows are requested before the convolution whose output they scale)
+template <bool RES, bool RELU>
+__device__ __forceinline__ void ln_apply(float (&x)[GP], float mu, float rs, const float (&wv)[GP], const float (&bv)[GP],
+                                         const float (&res)[GP]) {
 #pragma unroll
     for (int p = 0; p < GP; ++p) {
         float y = (x[p] - mu) * rs * wv[p] + bv[p];
-        if (res) y += res[p];
-        x[p] = relu ? fmaxf(y, 0.f) : y;
+        if (RES) y += res[p];
+        x[p] = RELU ? fmaxf(y, 0.f) : y;
     }
 }
 
@@ -90,49 +91,81 @@ __global__ __launch_bounds__(256) void gate_wave_fwd_kernel(const float* __restr
                                                             float* __restrict__ sblk, int N, int A, float eps)
 {
     const int lane = threadIdx.x & 63;
-    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (n >= N) return;                                          // (wave-uniform; no barrier in this kernel)
+    const int n = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));      // wave-uniform: scalar addressing
+    if (n >= N) return;                                          // (no barrier in this kernel)
     const int an = n % A;
     const size_t row = (size_t)n * GCP + lane * GP, slab = (size_t)N * GCP;
-    float s[GP], a[GP];
+    float s[GP], a[GP], wv[GP], bv[GP];
+    load_row(w.p[0] + lane * GP, wv); load_row(w.p[1] + lane * GP, bv);
     load_row(x + row, s);
     float mu, rs;
     plane_stats(s, eps, mu, rs);
-    ln_apply(s, mu, rs, w.p[0] + lane * GP, w.p[1] + lane * GP, nullptr, false);
+    ln_apply<false, false>(s, mu, rs, wv, bv, s);
+#pragma unroll
     for (int b = 0; b < 4; ++b) {
         const float* const* q = w.p + 2 + 8 * b;
         if (sblk) store_row(sblk + (size_t)b * slab + row, s);
+        load_row(q[2] + lane * GP, wv); load_row(q[3] + lane * GP, bv);                   // LN1's rows: in flight during conv1
+        __builtin_amdgcn_sched_barrier(0);
         dwconv(s, q[0] + an * 9, q[1][an], false, a);
         plane_stats(a, eps, mu, rs);
-        ln_apply(a, mu, rs, q[2] + lane * GP, q[3] + lane * GP, nullptr, true);
+        ln_apply<false, true>(a, mu, rs, wv, bv, s);
+        load_row(q[6] + lane * GP, wv); load_row(q[7] + lane * GP, bv);                   // LN2's rows: in flight during conv2
+        __builtin_amdgcn_sched_barrier(0);
         float t[GP];
         dwconv(a, q[4] + an * 9, q[5][an], false, t);
         plane_stats(t, eps, mu, rs);
-        ln_apply(t, mu, rs, q[6] + lane * GP, q[7] + lane * GP, s, true);
+        ln_apply<true, true>(t, mu, rs, wv, bv, s);
 #pragma unroll
         for (int p = 0; p < GP; ++p) s[p] = t[p];
     }
     store_row(out + row, s);
 }
 
-// LayerNorm backward: g = upstream gradient of the LN output, xin = its input; writes the affine partials (g * xhat, g) of this plane
-// and returns dx in g
-__device__ __forceinline__ void ln_backward(float (&g)[GP], const float (&xin)[GP], float mu, float rs, const float* __restrict__ gamma,
-                                            float* __restrict__ part_w, float* __restrict__ part_b) {
-    float gm[GP], pw[GP];
-    load_row(gamma, gm);
+constexpr int BW = 4;                        // planes (= wavefronts) per workgroup of the backward kernel
+
+// The LayerNorm affine gradients are sums over ALL planes: every plane's (g * xhat, g) rows used to travel to HBM (18 rows of
+// 9 KB per plane: 199 MB per launch written, and read again by the column reduce - more than everything else the backward
+// moves).  The BW planes of a workgroup are folded first, in a fixed order (deterministic): each wave parks its row in LDS,
+// wave k then adds the BW copies of elements [576 k, 576 k + 576) and writes that quarter of the workgroup's partial row.
+__device__ __forceinline__ void fold_store(const float (&v)[GP], bool live, float* __restrict__ red, float* __restrict__ dst, int wave, int lane) {
+    float z[GP];
+#pragma unroll
+    for (int p = 0; p < GP; ++p) z[p] = live ? v[p] : 0.f;        // planes past N contribute zeros
+    store_row(red + wave * GCP + lane * GP, z);
+    __syncthreads();
+    const int base = wave * (GCP / BW) + lane * (GP / BW);        // 9 consecutive elements
+#pragma unroll
+    for (int i = 0; i < GP / BW; ++i) {
+        float acc = red[base + i];
+#pragma unroll
+        for (int j = 1; j < BW; ++j) acc += red[j * GCP + base + i];
+        dst[base + i] = acc;
+    }
+    __syncthreads();
+}
+
+// LayerNorm backward: g = upstream gradient of the LN output, xin = its input; folds the affine partials (g * xhat, g) of the
+// workgroup's planes into part_w / part_b and returns dx in g
+__device__ __forceinline__ void ln_backward(float (&g)[GP], const float (&xin)[GP], float mu, float rs, const float (&gamma)[GP],
+                                            bool live, float* __restrict__ red, float* __restrict__ part_w, float* __restrict__ part_b,
+                                            int wave, int lane) {
+    float gm[GP];
+    {
+        float pw[GP];
+#pragma unroll
+        for (int p = 0; p < GP; ++p) pw[p] = g[p] * ((xin[p] - mu) * rs);
+        fold_store(pw, live, red, part_w, wave, lane);
+    }
+    fold_store(g, live, red, part_b, wave, lane);
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int p = 0; p < GP; ++p) {
-        const float xh = (xin[p] - mu) * rs;
-        pw[p] = g[p] * xh;
-        const float gw = g[p] * gm[p];
-        s1 += gw; s2 += gw * xh;
+        const float gw = g[p] * gamma[p];
+        s1 += gw; s2 += gw * ((xin[p] - mu) * rs);
         gm[p] = gw;
     }
-    store_row(part_w, pw);
-    store_row(part_b, g);
-    s1 = wave_sum(s1) / (float)GCP; s2 = wave_sum(s2) / (float)GCP;
+    s1 = wave_sum(s1) * (1.0f / (float)GCP); s2 = wave_sum(s2) * (1.0f / (float)GCP);
 #pragma unroll
     for (int p = 0; p < GP; ++p) g[p] = rs * (gm[p] - s1 - (xin[p] - mu) * rs * s2);
 }
@@ -164,26 +197,28 @@ __device__ __forceinline__ void filter_grad(const float (&src)[GP], const float 
     }
 }
 
-// 128 threads = 2 planes per workgroup, two wave-private LDS planes each (4 x 9 KB per workgroup).
-// lnpart: [N][18][CP] per-plane partial gradients of the 9 LayerNorms' (weight, bias); fpart [N][8][10] filter partials (N > A)
-__global__ __launch_bounds__(128, 2) void gate_wave_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ x,
+// 256 threads = 4 planes per workgroup; LDS: one wave-private parked plane each (the residual gradient) + the fold buffer.
+// lnpart: [ceil(N/4)][18][CP] per-WORKGROUP partial gradients of the 9 LayerNorms' (weight, bias); fpart [N][8][10] filter partials (N > A)
+__global__ __launch_bounds__(256, 2) void gate_wave_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ x,
                                                                const float* __restrict__ out, GateParams w,
                                                                const float* __restrict__ sblk, GateGrads dg, float* __restrict__ lnpart,
                                                                float* __restrict__ fpart, int N, int A, float eps, int accumulate)
 {
-    __shared__ float park[2][2][GCP];                            // [wave][slot]: the lane's rows, private to the wave
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int n = blockIdx.x * 2 + wv;
-    if (n >= N) return;                                          // (wave-uniform; no barrier in this kernel)
+    __shared__ float park[BW][GCP];                              // the lane's rows, private to the wave
+    __shared__ float red[BW * GCP];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n_raw = __builtin_amdgcn_readfirstlane(blockIdx.x * BW + (threadIdx.x >> 6));
+    const bool live = n_raw < N;                                 // a wave past the last plane runs along (barriers) on plane N-1, writes nothing
+    const int n = live ? n_raw : N - 1;
     const int an = n % A;
     const size_t row = (size_t)n * GCP + lane * GP, slab = (size_t)N * GCP;
-    float* lp = lnpart + (size_t)n * 18 * GCP + lane * GP;
+    float* lp = lnpart + (size_t)blockIdx.x * 18 * GCP;          // the workgroup's folded partial rows
     const bool direct_f = N == A;                                // this wave is the only one that touches its anchor's filter gradients
     float* fp = fpart + (size_t)n * 80;
-    float* park_c1 = &park[wv][0][lane * GP];
-    float* park_gr = &park[wv][1][lane * GP];
+    float* park_gr = &park[wv][lane * GP];
     float g[GP];
     load_row(gout + row, g);
+#pragma unroll
     for (int b = 3; b >= 0; --b) {
         const float* const* q = w.p + 2 + 8 * b;
         float* const* dq = dg.p + 2 + 8 * b;
@@ -191,44 +226,54 @@ __global__ __launch_bounds__(128, 2) void gate_wave_bwd_kernel(const float* __re
         float u[GP], c2[GP];
         float mu1, rs1, mu2, rs2;
         {
-            float s[GP], c1[GP];
+            float s[GP], c1[GP], wv1[GP], bv1[GP];
             load_row(sblk + (size_t)b * slab + row, s);
+            load_row(q[2] + lane * GP, wv1); load_row(q[3] + lane * GP, bv1);                    // LN1's rows: in flight during conv1
+            __builtin_amdgcn_sched_barrier(0);
             dwconv(s, q[0] + an * 9, q[1][an], false, c1);
-            store_row(park_c1, c1);                              // LN1's input: needed again for its backward
             plane_stats(c1, eps, mu1, rs1);
 #pragma unroll
             for (int p = 0; p < GP; ++p) u[p] = c1[p];
-            ln_apply(u, mu1, rs1, q[2] + lane * GP, q[3] + lane * GP, nullptr, true);            // u = relu(LN1(c1))
+            ln_apply<false, true>(u, mu1, rs1, wv1, bv1, s);                                     // u = relu(LN1(c1))
+        }
+        float gam[GP];
+        {
+            float o[GP];
+            // through the block's output relu: the mask is the forward's own output (the next block's saved input, or `out`)
+            load_row(b == 3 ? out + row : sblk + (size_t)(b + 1) * slab + row, o);
+            load_row(q[6] + lane * GP, gam);                                                     // LN2's weight: in flight during conv2
+            __builtin_amdgcn_sched_barrier(0);
             dwconv(u, q[4] + an * 9, q[5][an], false, c2);
             plane_stats(c2, eps, mu2, rs2);
-            // through the block's output relu: the mask is the forward's own output (the next block's saved input, or `out`)
-            float o[GP];
-            load_row(b == 3 ? out + row : sblk + (size_t)(b + 1) * slab + row, o);
 #pragma unroll
             for (int p = 0; p < GP; ++p) g[p] = o[p] > 0.f ? g[p] : 0.f;
         }
         store_row(park_gr, g);                                   // the residual path's gradient
         // ---- LN2 backward (input c2), conv2 backward (input u) ----
-        ln_backward(g, c2, mu2, rs2, q[6] + lane * GP, lp + (size_t)(2 + 4 * b + 2) * GCP, lp + (size_t)(2 + 4 * b + 3) * GCP);
-        if (direct_f) filter_grad(u, g, dq[4] + an * 9, dq[5] + an, accumulate, lane);
-        else filter_grad(u, g, fp + (2 * b + 1) * 10, fp + (2 * b + 1) * 10 + 9, 0, lane);
+        ln_backward(g, c2, mu2, rs2, gam, live, red, lp + (size_t)(2 + 4 * b + 2) * GCP, lp + (size_t)(2 + 4 * b + 3) * GCP, wv, lane);
+        if (live) {
+            if (direct_f) filter_grad(u, g, dq[4] + an * 9, dq[5] + an, accumulate, lane);
+            else filter_grad(u, g, fp + (2 * b + 1) * 10, fp + (2 * b + 1) * 10 + 9, 0, lane);
+        }
         {
             float dv[GP];
             dwconv(g, q[4] + an * 9, 0.f, true, dv);
 #pragma unroll
             for (int p = 0; p < GP; ++p) g[p] = u[p] > 0.f ? dv[p] : 0.f;                         // through the inner relu
         }
-        // ---- LN1 backward (input c1, parked), conv1 backward (input s_b, re-read) ----
+        // ---- LN1 backward (input c1: conv1 of the re-read s_b once more - arithmetic is cheap, a parked plane is not),
+        //      conv1 backward (input s_b) ----
         {
-            float c1[GP];
-            load_row(park_c1, c1);
-            ln_backward(g, c1, mu1, rs1, q[2] + lane * GP, lp + (size_t)(2 + 4 * b + 0) * GCP, lp + (size_t)(2 + 4 * b + 1) * GCP);
-        }
-        {
-            float s[GP];
+            float s[GP], c1[GP];
             load_row(sblk + (size_t)b * slab + row, s);
-            if (direct_f) filter_grad(s, g, dq[0] + an * 9, dq[1] + an, accumulate, lane);
-            else filter_grad(s, g, fp + (2 * b) * 10, fp + (2 * b) * 10 + 9, 0, lane);
+            load_row(q[2] + lane * GP, gam);
+            __builtin_amdgcn_sched_barrier(0);
+            dwconv(s, q[0] + an * 9, q[1][an], false, c1);
+            ln_backward(g, c1, mu1, rs1, gam, live, red, lp + (size_t)(2 + 4 * b + 0) * GCP, lp + (size_t)(2 + 4 * b + 1) * GCP, wv, lane);
+            if (live) {
+                if (direct_f) filter_grad(s, g, dq[0] + an * 9, dq[1] + an, accumulate, lane);
+                else filter_grad(s, g, fp + (2 * b) * 10, fp + (2 * b) * 10 + 9, 0, lane);
+            }
         }
         {
             float dv[GP], gr[GP];
@@ -246,8 +291,8 @@ __global__ __launch_bounds__(128, 2) void gate_wave_bwd_kernel(const float* __re
         plane_stats(a, eps, mu, rs);
 #pragma unroll
         for (int p = 0; p < GP; ++p) pw[p] = g[p] * ((a[p] - mu) * rs);
-        store_row(lp, pw);
-        store_row(lp + GCP, g);
+        fold_store(pw, live, red, lp, wv, lane);
+        fold_store(g, live, red, lp + GCP, wv, lane);
     }
 }
 
@@ -256,6 +301,7 @@ __global__ __launch_bounds__(128, 2) void gate_wave_bwd_kernel(const float* __re
 // The wave-per-plane forms of phnet_gate_stack_fwd / _bwd (gate.hip documents arguments and layouts); C = 64, P = 36 only.
 // saved (training): the first 4 planes-slabs [4][N][C*P] receive the block inputs s_0..s_3 - all the backward needs.
 PHNET_API int phnet_gate_wave_applies(int32_t C, int32_t P) { return C == GC && P == GP; }
+PHNET_API int phnet_gate_wave_partial_planes(int32_t N) { return (N + BW - 1) / BW; }
 
 PHNET_API int phnet_gate_wave_fwd(const float* x, const float* const* params, float* out, float* saved,
                                   int32_t N, int32_t anchors, float eps, void* stream)
@@ -267,8 +313,9 @@ PHNET_API int phnet_gate_wave_fwd(const float* x, const float* const* params, fl
     return phnet_launch_status();
 }
 
-// workspace: [N][18][C*P] LayerNorm affine partials + [N][80] filter partials (phnet_gate_stack_bwd_workspace bytes); the
-// caller folds them with the reduce kernels of gate.hip (phnet_gate_stack_reduce).
+// workspace (phnet_gate_stack_bwd_workspace bytes): [ceil(N/4)][18][C*P] LayerNorm affine partials, folded per workgroup of four
+// planes, then - at the SAME offset as the generic kernel's, 18*N*C*P floats in - [N][80] filter partials; phnet_gate_stack_bwd
+// folds them with the reduce kernels of gate.hip (phnet_gate_wave_partial_planes = how many partial planes the column reduce reads).
 PHNET_API int phnet_gate_wave_bwd(const float* gout, const float* x, const float* out, const float* const* params, const float* saved,
                                   float* const* grads, int32_t N, int32_t anchors, float eps, int32_t accumulate,
                                   void* workspace, void* stream)
@@ -277,7 +324,7 @@ PHNET_API int phnet_gate_wave_bwd(const float* gout, const float* x, const float
     GateParams w; GateGrads dg;
     for (int i = 0; i < NPARAM; ++i) { w.p[i] = params[i]; dg.p[i] = grads[i]; if (!params[i] || !grads[i]) return PHNET_ERR_ARG; }
     float* fpart = (float*)workspace + (size_t)18 * N * GCP;
-    hipLaunchKernelGGL(gate_wave_bwd_kernel, dim3((N + 1) / 2), dim3(128), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(gate_wave_bwd_kernel, dim3((N + BW - 1) / BW), dim3(64 * BW), 0, (hipStream_t)stream,
                        gout, x, out, w, saved, dg, (float*)workspace, fpart, N, anchors, eps, accumulate);
     return phnet_launch_status();
 }
