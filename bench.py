@@ -462,22 +462,36 @@ def main():
             total_gemm_s = sum(a[2] for a in agg.values())
             sym, (n, fl, sec) = max(agg.items(), key=lambda kv: kv[1][2])
             peak, mfma_dtype, peak_note = GEMM_PEAK[args.mma]
-            prof = {}
-            try:                                           # separate rocprofv3 --pmc passes of this bench (profiles/README.md)
-                prof = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")))
-            except Exception:                              # noqa: BLE001
-                prof = {}
+            # counters from separate rocprofv3 --pmc passes of this bench (tests/tools/r03_profiles.sh): quoted only when they were
+            # taken on the SAME kernel sources as the ones running now (sha256 over phnet_amd/csrc), null otherwise
+            prof, prof_note = {}, None
+            try:
+                from tests.tools.kernel_sha import kernel_sources_sha
+                prof = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_summary.json")))
+                if prof.get("kernel_sources_sha256") != kernel_sources_sha(ROOT):
+                    prof_note = ("profiles/r03_pmc_summary.json was taken on other kernel sources (sha256 "
+                                 f"{str(prof.get('kernel_sources_sha256'))[:12]}... vs {kernel_sources_sha(ROOT)[:12]}... now): counters not quoted")
+                    prof = {}
+            except Exception as e:                         # noqa: BLE001
+                prof, prof_note = {}, f"no counter summary: {type(e).__name__}"
             traffic = (prof.get("traffic", {}).get(sym) or {}).get("hbm_bytes_per_launch_corrected")
             mfma_util = prof.get("backbone_conv_mfma_util")
+            # algorithmic bytes of the symbol's launches, averaged over the SAME launches the counters average over: every operand
+            # read once + the result written once (f32 activations; packed weights of conv3p: 6 bytes per element)
+            alg = [r[7] for r in records if r[0] == sym and len(r) > 7 and r[7]]
+            alg_bytes = (sum(alg) / len(alg)) if alg else None
             ach = fl / sec / 1e12
             roof = {"bound": "mfma", "kernel": sym, "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                     "frac": round(ach / peak, 4), "traffic": traffic,
+                    "algorithmic_bytes_per_launch": int(alg_bytes) if alg_bytes else None,
+                    "traffic_over_algorithmic": round(traffic / alg_bytes, 2) if (traffic and alg_bytes) else None,
+                    "counters_note": prof_note,
                     "peak_note": f"algorithmic (f32-product) TFLOP/s this arithmetic reaches with the matrix pipe always busy: {peak_note}; "
                                  "`achieved` counts each f32 multiply-add once, whatever number of MFMAs it costs",
                     "frac_of_f32_mfma_peak": round(ach / F32_MFMA_PEAK_TFLOPS, 4),
-                    "traffic_note": "HBM bytes per launch of this kernel symbol from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                                    "passes of this bench (profiles/r02_pmc_summary.json; FETCH_SIZE doubled per the gfx950 "
-                                    "correction for 16-B/lane streaming reads)" if traffic else None,
+                    "traffic_note": "HBM bytes per launch of this kernel symbol (average over its launches of a step) from separate "
+                                    "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench (profiles/r03_pmc_summary.json, taken on "
+                                    "these kernel sources; FETCH_SIZE doubled per the gfx950 correction for 16-B/lane streaming reads)" if traffic else None,
                     "launches": n, "avg_launch_us": round(sec / n * 1e6, 2), "gflop_per_launch": round(fl / n / 1e9, 3),
                     "mfma_dtype": mfma_dtype,
                     "all_gemm_kernels": {k: {"launches": v[0], "TFLOP/s": round(v[1] / v[2] / 1e12, 2), "ms_per_step": round(v[2] / steps_timed * 1e3, 3)}

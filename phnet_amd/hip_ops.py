@@ -37,7 +37,7 @@ def _gemm_symbol(m, co, k, ws_bytes, dgrad, ci_a, in_dil=1, taps3=False):
             f"{_MMA_MODE}, {pf}, {'true' if buf else 'false'}>", sp.value)
 
 
-def _timed_launch(sym_fn, flops, launch, shape=None):
+def _timed_launch(sym_fn, flops, launch, shape=None, nbytes=None):
     """Runs `launch()`.  With the timer on, also records (symbol, split-K factor, FLOPs, start event, end event, launch):
     bench.py re-launches the recorded closures in isolation inside small hipGraphs to get device-side durations that
     are free of host launch gaps (the event pair around a live eager launch includes them for microsecond kernels)."""
@@ -48,7 +48,7 @@ def _timed_launch(sym_fn, flops, launch, shape=None):
     e0.record()
     out = launch()
     e1.record()
-    TIMER.append((sym, splits, flops, e0, e1, launch, shape))     # shape: ("fwd" | "dgrad" | "wgrad" | "linbwd", GEMM rows, cols, depth) for tests/tools/gemm_shapes.py
+    TIMER.append((sym, splits, flops, e0, e1, launch, shape, nbytes))     # shape: ("fwd" | "dgrad" | "wgrad" | "linbwd", GEMM rows, cols, depth) for tests/tools/gemm_shapes.py; nbytes: algorithmic HBM bytes
     return out
 
 
@@ -167,12 +167,12 @@ def conv2d_fwd(x, w, bias, stride: int, pad: int, relu: bool = False, out: Optio
         _timed_launch(lambda: _gemm_symbol(m, co, k, need, False, ci, taps3=(r == 3 and s == 3 and stride == 1 and pad == 1)), 2.0 * m * co * k,
                       lambda: check(lib().phnet_conv2d_fwd_fused(_ptr(x), _ptr(w), _ptr(bias), _ptr(addend), _ptr(out), _ptr(part), n, hi, wi,
                                                                  ci, co, r, s, stride, pad, int(relu), _ptr(ws), need, _stream()),
-                                    "phnet_conv2d_fwd_fused"), shape=("fwd", m, co, k, r))
+                                    "phnet_conv2d_fwd_fused"), shape=("fwd", m, co, k, r), nbytes=4.0 * (n * hi * wi * ci + m * co + co * k))
         return (out, (part, nblk)) if stats else out
     _timed_launch(lambda: _gemm_symbol(m, co, k, need, False, ci, taps3=(r == 3 and s == 3 and stride == 1 and pad == 1)), 2.0 * m * co * k,
                   lambda: check(lib().phnet_conv2d_fwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(out), n, hi, wi, ci, co, r, s, stride,
                                                        pad, int(relu), _ptr(ws), need, _stream()), "phnet_conv2d_fwd"),
-                  shape=("fwd", m, co, k, r))
+                  shape=("fwd", m, co, k, r), nbytes=4.0 * (n * hi * wi * ci + m * co + co * k))
     return out
 
 
@@ -250,7 +250,8 @@ def conv3p(x: torch.Tensor, packed: torch.Tensor, nn: int, dgrad: bool = False, 
                   2.0 * m * nn * 9 * ca,
                   lambda: check(lib().phnet_conv3p_fwd(_ptr(x), _ptr(packed), _ptr(bias), _ptr(addend), _ptr(out), _ptr(part), n, h, w_, ca, nn,
                                                        int(relu), _ptr(ws), need, _stream()), "phnet_conv3p_fwd"),
-                  shape=("dgrad" if dgrad else "fwd", m, nn, 9 * ca, 3))
+                  shape=("dgrad" if dgrad else "fwd", m, nn, 9 * ca, 3),
+                  nbytes=4.0 * m * (ca + nn) + 6.0 * 9 * ca * nn + (4.0 * m * nn if addend is not None else 0.0))
     return (out, (part, nblk)) if stats else out
 
 
@@ -266,7 +267,7 @@ def conv2d_dgrad(dy, w, in_hw: Tuple[int, int], stride: int, pad: int, addend: O
     _timed_launch(lambda: _gemm_symbol(m, ci, k, need, True, co, stride, taps3=(r == 3 and s == 3 and stride == 1 and pad == 1)), 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * co * r * s * ci,
                   lambda: check(lib().phnet_conv2d_dgrad(_ptr(dy), _ptr(w), _ptr(addend), _ptr(dx), n, hi, wi, ci, co, r, s, stride,
                                                          pad, _ptr(ws), need, _stream()), "phnet_conv2d_dgrad"),
-                  shape=("dgrad", m, ci, k, r))
+                  shape=("dgrad", m, ci, k, r), nbytes=4.0 * (dy.numel() + m * ci + co * r * s * ci))
     return dx
 
 
@@ -297,7 +298,7 @@ def conv2d_wgrad(dy, x, w_shape, stride: int, pad: int, dw: Optional[torch.Tenso
                   2.0 * n * ho * wo * co * r * s * ci,
                   lambda: check(lib().phnet_conv2d_wgrad(_ptr(dy), _ptr(x), _ptr(dw), _ptr(dbias), n, hi, wi, ci, co, r, s, stride,
                                                          pad, int(accumulate), _ptr(ws), need, _stream()), "phnet_conv2d_wgrad"),
-                  shape=("wgrad", co, r * s * ci, n * ho * wo, r))
+                  shape=("wgrad", co, r * s * ci, n * ho * wo, r), nbytes=4.0 * (dy.numel() + x.numel() + co * r * s * ci))
     return dw
 
 

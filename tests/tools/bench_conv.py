@@ -84,8 +84,14 @@ def main():
                 if bm and sp > 1 and (M // bm + 1) * (Co // bn + 1) * sp > 4096: continue
                 lib().phnet_tune_force_conv_tile(bm, bn, sp)
                 try:
-                    tf = timeit(lambda: K.conv2d_fwd(x, w, None, st, pad))
-                    td = timeit(lambda: K.conv2d_dgrad(gy, w, (Hi, Wi), st, pad)) if Ci >= 64 else float("nan")
+                    if "--packed" in sys.argv and R == 3 and st == 1 and K.conv3p_applies(M, Ci, Co):
+                        # what the trunk schedule runs since round 3: forward / data gradient on packed weights (csrc/conv3p.hip)
+                        pf_, pd_ = K.conv3p_pack(w, False), K.conv3p_pack(w, True)
+                        tf = timeit(lambda: K.conv3p(x, pf_, Co))
+                        td = timeit(lambda: K.conv3p(gy, pd_, Ci, dgrad=True))
+                    else:
+                        tf = timeit(lambda: K.conv2d_fwd(x, w, None, st, pad))
+                        td = timeit(lambda: K.conv2d_dgrad(gy, w, (Hi, Wi), st, pad)) if Ci >= 64 else float("nan")
                 except RuntimeError as e:
                     continue
                 res.append((f'{bm:3d}x{bn:3d} kt{kt_:2d}', bn, sp, tf, td))

@@ -134,8 +134,9 @@ def main():
         cpu_c = (time.perf_counter() - t0) / 5
         crit[name] = {"ms_per_frame_fwd_bwd_hipgraph": round(dtg * 1e3, 3), "ms_per_frame_fwd_bwd_eager": round(dtc * 1e3, 3),
                       "ms_per_frame_fwd_bwd_cpu_oracle": round(cpu_c * 1e3, 3),
-                      "note": "device: HIP assignment kernel(s) + tensor-op loss under autograd, no host sync; eager = bound by the host's "
-                              "operator dispatch (~450 tiny launches), hipGraph = how a captured training step runs it; bound: launch latency"}
+                      "note": "device (round 3): phnet_frame_loss_variant - assignment, every loss term and every input gradient in two "
+                              "launches per frame (csrc/loss_variants.hip; round 2: ~450 ATen launches, 2.06 / 1.85 ms per frame graph-"
+                              "replayed); the rest of a frame's time is the autograd shell (gradient scaling and view launches); bound: launch latency"}
     out["f2_criterion_variants"] = crit
 
     # ---- 8(f) rank 3: the CULane-style evaluator on synthetic OpenLane-V sized label files (1280 x 1920 canvas, lane width 30) ----
