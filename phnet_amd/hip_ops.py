@@ -246,7 +246,8 @@ def conv3p(x: torch.Tensor, packed: torch.Tensor, nn: int, dgrad: bool = False, 
     if addend is not None:
         _req(addend, name="addend")
         assert addend.shape == out.shape
-    _timed_launch(lambda: ("conv3p_kernel", int(lib().phnet_conv3p_splits(m, ca, nn, need))),        # one symbol, as rocprofv3 sees it
+    # the symbol rocprofv3 sees: <2> = the 128-column tile (csrc/conv3p.hip p3_plan: >= 128 output channels and >= 16384 pixels)
+    _timed_launch(lambda: (f"conv3p_kernel<{2 if (nn % 128 == 0 and m >= 16384) else 1}>", int(lib().phnet_conv3p_splits(m, ca, nn, need))),
                   2.0 * m * nn * 9 * ca,
                   lambda: check(lib().phnet_conv3p_fwd(_ptr(x), _ptr(packed), _ptr(bias), _ptr(addend), _ptr(out), _ptr(part), n, h, w_, ca, nn,
                                                        int(relu), _ptr(ws), need, _stream()), "phnet_conv3p_fwd"),
