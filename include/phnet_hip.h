@@ -418,6 +418,13 @@ int phnet_dyn_bmm_ln_relu_bwd(const float* dy, const float* x, const float* w, c
                               const float* gamma, float* dx, float* dw, float* dgamma, float* dbeta,
                               int32_t N, int32_t P, int32_t K, int32_t J, float eps, int32_t param_accumulate,
                               void* workspace, uint64_t ws_bytes, void* stream);
+/* the matrix-pipe forms (csrc/dyn_mfma.hip: one wavefront per anchor, v_mfma_f32_16x16x4_f32, no LDS); the two calls above
+ * dispatch to them where phnet_dyn_mfma_applies (P <= 36, (K, J) = (64, 128) or (128, 64)) */
+int phnet_dyn_mfma_applies(int32_t P, int32_t K, int32_t J);
+int phnet_dyn_mfma_fwd(const float* x, const float* w, const float* gamma, const float* beta, float* y, float* stats,
+                       int32_t N, int32_t P, int32_t K, int32_t J, float eps, void* stream);
+int phnet_dyn_mfma_bwd(const float* dy, const float* x, const float* w, const float* y, const float* stats, const float* gamma,
+                       float* dx, float* dw, float* lnpart, int32_t N, int32_t P, int32_t K, int32_t J, void* stream);
 
 /* ---- bias gradients: column sums of [M][C] ---- */
 uint64_t phnet_colsum_workspace(int64_t M, int32_t C);

@@ -27,6 +27,9 @@ int phnet_conv3p_tune(int32_t target_workgroups);
 /* routing gate's depth-wise stack: 1 = one wavefront per plane (csrc/gate_wave.hip, default where C = 64, P = 36), 0 = the generic
  * one-workgroup-per-plane kernels (csrc/gate.hip) */
 int phnet_tune_gate_wave(int32_t on);
+/* per-anchor products of the dynamic head: 1 = matrix-pipe kernels, one wavefront per anchor (csrc/dyn_mfma.hip, default where they
+ * apply), 0 = the LDS / FMA kernels of csrc/dynhead.hip */
+int phnet_tune_dyn_mfma(int32_t on);
 
 #ifdef __cplusplus
 }

@@ -260,12 +260,21 @@ int launch_bwd(const float* dy, const float* x, const float* w, const float* y, 
 
 }  // namespace
 
+extern "C" int phnet_dyn_mfma_applies(int32_t P, int32_t K, int32_t J);
+extern "C" int phnet_dyn_mfma_fwd(const float* x, const float* w, const float* gamma, const float* beta, float* y, float* stats,
+                                  int32_t N, int32_t P, int32_t K, int32_t J, float eps, void* stream);
+extern "C" int phnet_dyn_mfma_bwd(const float* dy, const float* x, const float* w, const float* y, const float* stats, const float* gamma,
+                                  float* dx, float* dw, float* lnpart, int32_t N, int32_t P, int32_t K, int32_t J, void* stream);
+static int g_dyn_mfma = 1;       // matrix-pipe forward (dyn_mfma.hip) where it applies; phnet_tune_dyn_mfma(0) = the LDS / FMA kernels
+PHNET_API int phnet_tune_dyn_mfma(int32_t on) { g_dyn_mfma = on != 0; return PHNET_OK; }
+
 // y[n] = relu(LayerNorm_J(x[n] @ w[n]) * gamma + beta);  x [N][P][K], w [N][K][J], y [N][P][J], stats [N][P][2]
 // (mean, rstd; may be NULL for inference).  P <= 36; (K, J) in {(64,128), (128,64), (32,64), (64,32)}.
 PHNET_API int phnet_dyn_bmm_ln_relu_fwd(const float* x, const float* w, const float* gamma, const float* beta, float* y,
                                         float* stats, int32_t N, int32_t P, int32_t K, int32_t J, float eps, void* stream)
 {
     if (N < 1 || P < 1 || P > PMAX || !x || !w || !gamma || !beta || !y) return PHNET_ERR_ARG;
+    if (g_dyn_mfma && phnet_dyn_mfma_applies(P, K, J)) return phnet_dyn_mfma_fwd(x, w, gamma, beta, y, stats, N, P, K, J, eps, stream);
     DynShape g{N, P, eps};
 #define CALL(K_, J_) return launch_fwd<K_, J_>(x, w, gamma, beta, y, stats, g, (hipStream_t)stream)
     DYN_DISPATCH(K, J, CALL)
@@ -285,9 +294,13 @@ PHNET_API int phnet_dyn_bmm_ln_relu_bwd(const float* dy, const float* x, const f
     DynShape g{N, P, eps};
     hipStream_t st = (hipStream_t)stream;
     int rc;
+    if (g_dyn_mfma && phnet_dyn_mfma_applies(P, K, J)) {
+        rc = phnet_dyn_mfma_bwd(dy, x, w, y, stats, gamma, dx, dw, (float*)workspace, N, P, K, J, stream);
+    } else {
 #define CALL(K_, J_) rc = launch_bwd<K_, J_>(dy, x, w, y, stats, gamma, dx, dw, (float*)workspace, g, st)
     DYN_DISPATCH(K, J, CALL)
 #undef CALL
+    }
     if (rc != PHNET_OK) return rc;
     hipLaunchKernelGGL(dyn_ln_grad_reduce_kernel, dim3((2 * J + 31) / 32), dim3(1024), 0, st, (const float*)workspace, dgamma, dbeta,
                        N, J, param_accumulate);
