@@ -77,7 +77,7 @@ def _pack_plan(enc, convs):
 
 def _conv3(x, w, packed, stats=False, bias=None, addend=None, relu=False):
     """3x3 / stride-1 forward: the packed-weight kernel when an image is at hand, else the generic entry point."""
-    if packed is not None:
+    if packed is not None and K.conv3p_applies(x.shape[0] * x.shape[1] * x.shape[2], w.shape[3], w.shape[0]):
         return K.conv3p(x, packed[False], w.shape[0], bias=bias, addend=addend, relu=relu, stats=stats)
     return K.conv2d_fwd(x, w, bias, 1, 1, relu=relu, addend=addend, stats=stats)
 
@@ -89,6 +89,10 @@ def _conv_bn(tape: list, x, conv: nn.Conv2d, bn, training: bool, relu: bool, res
     rec.w = w_override if w_override is not None else ohwi(conv.weight)
     rec.x_in = x
     rec.packed = packs.get(id(conv)) if packs is not None else None
+    if rec.packed is not None:                                 # (byte offsets of the packed kernel are 32-bit: huge batches take the generic path)
+        m_ = x.shape[0] * x.shape[1] * x.shape[2]
+        if not (K.conv3p_applies(m_, conv.in_channels, conv.out_channels) and K.conv3p_applies(m_, conv.out_channels, conv.in_channels)):
+            rec.packed = None
     mom = bn.momentum if bn.momentum is not None else 0.1
     rec.sync_count = None
     rec.relu, rec.has_res = relu, residual is not None
@@ -97,7 +101,7 @@ def _conv_bn(tape: list, x, conv: nn.Conv2d, bn, training: bool, relu: bool, res
         # statistic changes), residual add and ReLU in the GEMM epilogue - ONE launch per conv/BN/ReLU block, no
         # elementwise pass (resnet.py:79-95 in eval mode: y = relu(bn(conv(x)) + identity))
         wf, bf, pk = _folded(conv, bn, rec.w)
-        if pk is not None:
+        if pk is not None and K.conv3p_applies(x.shape[0] * x.shape[1] * x.shape[2], conv.in_channels, conv.out_channels):
             rec.c = rec.y = K.conv3p(x, pk, wf.shape[0], bias=bf, addend=residual, relu=relu)
         else:
             rec.c = rec.y = K.conv2d_fwd(x, wf, bf, rec.stride, rec.pad, relu=relu, addend=residual)
@@ -273,7 +277,8 @@ def encoder_bwd_schedule(ctx: _Tape, d3, d4, d5, stage_done: Optional[Callable[[
     for i in range(3):
         m = neck.fpn_convs[i].conv
         conv_wgrad_into(m.weight, douts[i], ctx.lats[i], ctx.out_w[i].shape, 1, 1, bias=m.bias)
-        if ctx.out_packs[i] is not None:
+        if ctx.out_packs[i] is not None and K.conv3p_applies(douts[i].shape[0] * douts[i].shape[1] * douts[i].shape[2],
+                                                             ctx.out_w[i].shape[0], ctx.out_w[i].shape[3]):
             dl.append(K.conv3p(douts[i], ctx.out_packs[i][True], ctx.out_w[i].shape[3], dgrad=True))
         else:
             dl.append(K.conv2d_dgrad(douts[i], ctx.out_w[i], tuple(ctx.lats[i].shape[1:3]), 1, 1))
