@@ -19,6 +19,7 @@
 // Roofline: MFMA-bound (f32-input MFMA, 157.3 TF/s dense).  Algorithmic FLOPs = 2*M*N*K.
 #include <type_traits>
 #include "igemm.h"
+#include "wgrad3s.h"
 static constexpr bool g_interleave = true;                   // MFMA / VALU interleave hints of the staged-split loops
 
 using namespace igemm;
@@ -997,6 +998,7 @@ __global__ __launch_bounds__(THREADS) void conv_wgrad_kernel(
 constexpr int W3_THREADS = 768;
 int g_wgrad3 = 1, g_wgrad3_target = 256;                     // tuning aids (phnet_tune_wgrad: bit 3 of arg 0 switches it off; a negative
 int g_wgrad3_bkw = 16;                                       // second argument sets its workgroup target, bit 4 selects 32-pixel steps)
+int g_wgrad3s = 1;                                           // producer / consumer variant (csrc/wgrad3s.hip) where no bias gradient is asked for; bit 5 switches it off
 template <int BKW> struct Wgrad3Lds {
     static constexpr int ROWS = BKW + 2;                     // X rows of a step: pixels pt-1 .. pt+BKW of the shifted image row
     static constexpr int PITCH = KStridedPlanes<64, BK>::PITCH;      // 192 bytes: 64 bf16 + pad (igemm.h)
@@ -1568,6 +1570,7 @@ PHNET_API int phnet_tune_wgrad(int32_t allow_bm128, int32_t target_blocks)
     g_wgrad_bm128 = allow_bm128 & 1; g_wgrad_smallp = !(allow_bm128 & 2); g_wgrad_bkw = (allow_bm128 & 4) ? 32 : 16;
     g_wgrad3 = !(allow_bm128 & 8);
     g_wgrad3_bkw = (allow_bm128 & 16) ? 32 : 16;
+    g_wgrad3s = !(allow_bm128 & 32);
     if (target_blocks < 0) g_wgrad3_target = -target_blocks;      // workgroup target of the three-taps 3x3 kernel
     else g_wgrad_target = target_blocks;
     return PHNET_OK;
@@ -1760,11 +1763,23 @@ PHNET_API int phnet_conv2d_wgrad(const float* dy, const float* x, float* dw, flo
         long splits = wgrad3_splits(P, Co, Ci);
         const long row = (long)Co * NC + Co;
         while (splits > 1 && (!workspace || (uint64_t)(splits * row * sizeof(float)) > ws_bytes)) --splits;
-        const int bkw = g_wgrad3_bkw == 16 ? 16 : 32;
+        const bool pc = g_wgrad3s && !dbias;                      // producer / consumer kernel
+        const int bkw = pc ? phnet_wgrad3s_kstep() : g_wgrad3_bkw == 16 ? 16 : 32;
         const long psteps = ceil_div64(P, bkw);
         g.splits = (int)splits;
         g.pix_per_split = (int)(ceil_div64(psteps, splits) * bkw);
         float* out = splits > 1 ? (float*)workspace : dw;
+        if (pc) {
+            Wgrad3sShape s{N, Hi, Wi, Ci, Co, g.splits, g.pix_per_split};
+            const int rc = phnet_wgrad3s_launch(dy, x, out, s, accumulate, st);
+            if (rc != PHNET_OK) return rc;
+            if (splits > 1) {
+                const long nw = (long)Co * NC, nb = Co;
+                hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div64((nw + nb) >> 2, 64)), dim3(256), 0, st,
+                                   (const float*)workspace, dw, (float*)nullptr, nw, nb, (int)splits, accumulate);
+            }
+            return phnet_launch_status();
+        }
         dim3 grid((unsigned)((Co / 64) * (Ci / 64) * 3), 1, (unsigned)splits);
         static bool attr = false;
         if (!attr) {

@@ -323,14 +323,24 @@ def test_wgrad_three_taps_kernel_vs_fp64(ops, bf16x3, case):
     ops.conv2d_wgrad(gyd, xd, shape, 1, 1, dw=dw, dbias=db, accumulate=True)
     close(dw, 2 * want, 2e-5)
     close(db, 2 * gy.sum(dim=(0, 2, 3)), 2e-5)
+    # without a bias gradient the producer / consumer variant runs (csrc/wgrad3s.hip: four extra waves stage, twelve multiply)
+    dw_pc = ops.conv2d_wgrad(gyd, xd, shape, 1, 1)
+    close(dw_pc, want, 2e-5)
+    ops.conv2d_wgrad(gyd, xd, shape, 1, 1, dw=dw_pc, accumulate=True)
+    close(dw_pc, 2 * want, 2e-5)
+    assert lib().phnet_tune_wgrad(1 | 32, 768) == 0                      # bit 5: the all-waves-stage kernel without a bias gradient
+    try:
+        close(ops.conv2d_wgrad(gyd, xd, shape, 1, 1), want, 2e-5)
+    finally:
+        assert lib().phnet_tune_wgrad(1, 768) == 0
     assert lib().phnet_tune_wgrad(1 | 8, 768) == 0                       # the generic kernel on the same operands
     try:
         dw_generic = ops.conv2d_wgrad(gyd, xd, shape, 1, 1)
     finally:
         assert lib().phnet_tune_wgrad(1, 768) == 0
     close(dw_generic, want, 2e-5)
-    for flags, target in ((1, 64), (1, 1024), (1 | 16, 256), (1 | 16, 1024)):      # other splits of the pixel range, down to one step;
-        assert lib().phnet_tune_wgrad(flags, -target) == 0                   # bit 4: 32-pixel instead of 16-pixel steps
+    for flags, target in ((1, 64), (1, 1024), (1 | 32, 64), (1 | 32 | 16, 256), (1 | 32 | 16, 1024)):      # other splits of the pixel range, down to
+        assert lib().phnet_tune_wgrad(flags, -target) == 0                   # one step; bit 4: 32-pixel instead of 16-pixel steps (bit 5 kernel)
         try:
             close(ops.conv2d_wgrad(gyd, xd, shape, 1, 1), want, 2e-5)
         finally:
