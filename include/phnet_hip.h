@@ -254,6 +254,16 @@ int phnet_frame_loss(const float* const* pred, const float* const* gate, const f
                      float liou_half_width, float liou_img_h, float liou_img_w,
                      float* loss, float* const* dpred, float* dgate,
                      int64_t* rows_by_col, int64_t* rows_sorted, float* focal, float* scalars, void* stream);
+/* The T frames of a clip in the SAME two launches (the criterion is called frame by frame, trainOLV3.py:150-171, and nothing
+ * flows from one frame's loss to the next): pred [T*6] / gate [T*3] / dpred [T*6] host arrays of device pointers, frame-major;
+ * tgt [T][L][6+S]; loss [T]; dgate [T][3][N]; rows_by_col / rows_sorted [T][6][L]; scratch focal [T][6][N], scalars [T][12].
+ * T <= 8.  phnet_frame_loss is the T = 1 case. */
+int phnet_clip_loss(const float* const* pred, const float* const* gate, const float* tgt, int32_t T,
+                    int32_t N, int32_t L, int32_t S, float img_w, float img_h,
+                    float cls_w, float reg_w, float iou_w,
+                    float liou_half_width, float liou_img_h, float liou_img_w,
+                    float* loss, float* const* dpred, float* dgate,
+                    int64_t* rows_by_col, int64_t* rows_sorted, float* focal, float* scalars, void* stream);
 /* the reference's other two criteria, fused the same way (csrc/loss_variants.hip; two launches per frame):
  * variant 1 = libs/utils/loss4OL.py:88-232 (per-pair terms summed by position, placed on the last stage's anchors),
  * variant 2 = libs/utils/loss4OLV2.py:12-186 (one-to-many assignment, up to 16 pairs per branch and stage).

@@ -23,18 +23,28 @@ struct LossParams {
     float liou_hw, liou_h, liou_w;
 };
 
+constexpr int MAXT = 8;                    // frames per launch (phnet_clip_loss)
+struct ClipParams { LossParams f[MAXT]; };
+
 __device__ __forceinline__ float wave_sum_all(float v) { return wave_sum(v); }
 
+// grid (6, T): blockIdx.y = frame; the per-frame outputs follow each other (tgt [T][L][6+S], rows [T][6][L], focal [T][6][N],
+// scalars [T][12])
 __global__ __launch_bounds__(NT) void frame_loss_terms_kernel(
-    LossParams p, const float* __restrict__ tgt, int64_t* __restrict__ rows_by_col_all, int64_t* __restrict__ rows_sorted_all,
+    ClipParams cp, const float* __restrict__ tgt, int64_t* __restrict__ rows_by_col_all, int64_t* __restrict__ rows_sorted_all,
     float* __restrict__ focal_all, float* __restrict__ scalars /* [6][2] reg, iou */)
 {
     extern __shared__ float cost[];
     __shared__ int s_rows[MAXL];
     __shared__ int s_nvalid;
+    const LossParams& p = cp.f[blockIdx.y];
     const int q = blockIdx.x;                     // pair index: branch*3 + stage
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int N = p.N, L = p.L, S = p.S, W = 6 + S;
+    {
+        const size_t f = blockIdx.y;
+        tgt += f * L * W; rows_by_col_all += f * 6 * L; rows_sorted_all += f * 6 * L; focal_all += f * 6 * N; scalars += f * 12;
+    }
     const float* pred = p.pred[q];
     float* dpred = p.dpred[q];
     int64_t* rows_by_col = rows_by_col_all + q * L;
@@ -138,13 +148,19 @@ __global__ __launch_bounds__(NT) void frame_loss_terms_kernel(
     }
 }
 
+// grid T: blockIdx.x = frame (loss [T], dgate [T][3][N])
 __global__ __launch_bounds__(NT) void frame_loss_finalize_kernel(
-    LossParams p, const float* __restrict__ focal_all, const float* __restrict__ scalars,
+    ClipParams cp, const float* __restrict__ focal_all, const float* __restrict__ scalars,
     float* __restrict__ loss_out, float* __restrict__ dgate /* [3][N] */)
 {
     __shared__ float diff[NT];
     __shared__ float red[4], s_delta;
+    const LossParams& p = cp.f[blockIdx.x];
     const int tid = threadIdx.x, N = p.N;
+    {
+        const size_t f = blockIdx.x;
+        focal_all += f * 6 * N; scalars += f * 12; loss_out += f; dgate += f * 3 * N;
+    }
     float ca = 0.f, cb = 0.f, d = 0.f;
     if (tid < N) {
         ca = (focal_all[0 * N + tid] + focal_all[1 * N + tid] + focal_all[2 * N + tid]) / 3.0f;
@@ -187,6 +203,42 @@ __global__ __launch_bounds__(NT) void frame_loss_finalize_kernel(
 // Outputs (caller-allocated): loss [1]; dpred[6] [N][6+S] and dgate [3][N] = d loss / d input (unit upstream);
 //   rows_by_col / rows_sorted [6][L] int64 (matched anchors per branch x stage, -1 padded);
 //   scratch: focal [6][N] f32, scalars [12] f32.
+static int fill_frame(LossParams& p, const float* const* pred, const float* const* gate, float* const* dpred, int32_t N, int32_t L, int32_t S,
+                      float img_w, float img_h, float cls_w, float reg_w, float iou_w, float liou_half_width, float liou_img_h, float liou_img_w)
+{
+    for (int i = 0; i < 6; ++i) { p.pred[i] = pred[i]; p.dpred[i] = dpred[i]; if (!pred[i] || !dpred[i]) return PHNET_ERR_ARG; }
+    for (int i = 0; i < 3; ++i) { p.gate[i] = gate[i]; if (!gate[i]) return PHNET_ERR_ARG; }
+    p.N = N; p.L = L; p.S = S; p.img_w = img_w; p.img_h = img_h;
+    p.cls_w = cls_w; p.reg_w = reg_w; p.iou_w = iou_w; p.alpha0 = 0.1f; p.alpha1 = 0.9f;
+    p.liou_hw = liou_half_width; p.liou_h = liou_img_h; p.liou_w = liou_img_w;
+    return PHNET_OK;
+}
+
+// The frames of a clip in the same two launches: frame t's loss needs nothing from frame t' (the criterion is called per frame,
+// trainOLV3.py:150-171, and the losses are added up).  pred [T*6], gate [T*3], dpred [T*6] pointers (frame-major); tgt [T][L][6+S];
+// loss [T]; dgate [T][3][N]; rows_by_col / rows_sorted [T][6][L]; scratch focal [T][6][N], scalars [T][12].  T <= 8.
+PHNET_API int phnet_clip_loss(const float* const* pred, const float* const* gate, const float* tgt, int32_t T,
+                              int32_t N, int32_t L, int32_t S, float img_w, float img_h,
+                              float cls_w, float reg_w, float iou_w,
+                              float liou_half_width, float liou_img_h, float liou_img_w,
+                              float* loss, float* const* dpred, float* dgate,
+                              int64_t* rows_by_col, int64_t* rows_sorted, float* focal, float* scalars, void* stream)
+{
+    if (T < 1 || T > MAXT || N < 1 || N > NT || L < 1 || L > MAXL || S < 3 || S > 250) return PHNET_ERR_ARG;
+    if (!pred || !gate || !tgt || !loss || !dpred || !dgate || !rows_by_col || !rows_sorted || !focal || !scalars) return PHNET_ERR_ARG;
+    ClipParams cp{};
+    for (int t = 0; t < T; ++t) {
+        const int rc = fill_frame(cp.f[t], pred + 6 * t, gate + 3 * t, dpred + 6 * t, N, L, S, img_w, img_h, cls_w, reg_w, iou_w,
+                                  liou_half_width, liou_img_h, liou_img_w);
+        if (rc != PHNET_OK) return rc;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(frame_loss_terms_kernel, dim3(6, T), dim3(NT), (size_t)N * MAXL * sizeof(float), st,
+                       cp, tgt, rows_by_col, rows_sorted, focal, scalars);
+    hipLaunchKernelGGL(frame_loss_finalize_kernel, dim3(T), dim3(NT), 0, st, cp, (const float*)focal, (const float*)scalars, loss, dgate);
+    return phnet_launch_status();
+}
+
 PHNET_API int phnet_frame_loss(const float* const* pred, const float* const* gate, const float* tgt,
                                int32_t N, int32_t L, int32_t S, float img_w, float img_h,
                                float cls_w, float reg_w, float iou_w,
@@ -194,17 +246,7 @@ PHNET_API int phnet_frame_loss(const float* const* pred, const float* const* gat
                                float* loss, float* const* dpred, float* dgate,
                                int64_t* rows_by_col, int64_t* rows_sorted, float* focal, float* scalars, void* stream)
 {
-    if (N < 1 || N > NT || L < 1 || L > MAXL || S < 3 || S > 250) return PHNET_ERR_ARG;
-    if (!pred || !gate || !tgt || !loss || !dpred || !dgate || !rows_by_col || !rows_sorted || !focal || !scalars) return PHNET_ERR_ARG;
-    LossParams p{};
-    for (int i = 0; i < 6; ++i) { p.pred[i] = pred[i]; p.dpred[i] = dpred[i]; if (!pred[i] || !dpred[i]) return PHNET_ERR_ARG; }
-    for (int i = 0; i < 3; ++i) { p.gate[i] = gate[i]; if (!gate[i]) return PHNET_ERR_ARG; }
-    p.N = N; p.L = L; p.S = S; p.img_w = img_w; p.img_h = img_h;
-    p.cls_w = cls_w; p.reg_w = reg_w; p.iou_w = iou_w; p.alpha0 = 0.1f; p.alpha1 = 0.9f;
-    p.liou_hw = liou_half_width; p.liou_h = liou_img_h; p.liou_w = liou_img_w;
-    hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(frame_loss_terms_kernel, dim3(6), dim3(NT), (size_t)N * MAXL * sizeof(float), st,
-                       p, tgt, rows_by_col, rows_sorted, focal, scalars);
-    hipLaunchKernelGGL(frame_loss_finalize_kernel, dim3(1), dim3(NT), 0, st, p, (const float*)focal, (const float*)scalars, loss, dgate);
-    return phnet_launch_status();
+    return phnet_clip_loss(pred, gate, tgt, 1, N, L, S, img_w, img_h, cls_w, reg_w, iou_w, liou_half_width, liou_img_h, liou_img_w, loss,
+                           dpred, dgate, rows_by_col, rows_sorted, focal, scalars, stream);
 }
+

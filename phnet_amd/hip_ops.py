@@ -699,6 +699,35 @@ def frame_loss(preds, gates, tgt, img_w, img_h, cls_w, reg_w, iou_w, liou_hw, li
     return loss, dpred, dgate, rows, srt
 
 
+def clip_loss(preds, gates, tgt, img_w, img_h, cls_w, reg_w, iou_w, liou_hw, liou_h, liou_w):
+    """frame_loss for the T frames of a clip in the same two launches.  preds: T x 6 x [N,6+S], gates: T x 3 x [N], tgt [T,L,6+S].
+    Returns (loss [T], dpred [T,6,N,6+S], dgate [T,3,N], rows_by_col [T,6,L] i64, rows_sorted [T,6,L] i64)."""
+    import ctypes
+    T = len(preds)
+    flat_p = [t for fr in preds for t in fr]
+    flat_g = [t for fr in gates for t in fr]
+    for t in flat_p + flat_g + [tgt]:
+        _req(t, name="loss input")
+    if len(flat_p) != 6 * T or len(flat_g) != 3 * T or tgt.shape[0] != T:
+        raise ValueError("clip_loss: 6 predictions and 3 gates per frame, one label block per frame")
+    n, w = flat_p[0].shape
+    L = tgt.shape[1]
+    dev = tgt.device
+    loss = torch.empty(T, dtype=torch.float32, device=dev)
+    dpred = torch.empty((T, 6, n, w), dtype=torch.float32, device=dev)
+    dgate = torch.empty((T, 3, n), dtype=torch.float32, device=dev)
+    rows = torch.empty((T, 6, L), dtype=torch.int64, device=dev)
+    srt = torch.empty((T, 6, L), dtype=torch.int64, device=dev)
+    scratch = torch.empty(T * (6 * n + 12), dtype=torch.float32, device=dev)
+    P = (ctypes.c_void_p * (6 * T))(*[t.data_ptr() for t in flat_p])
+    G = (ctypes.c_void_p * (3 * T))(*[t.data_ptr() for t in flat_g])
+    D = (ctypes.c_void_p * (6 * T))(*[dpred[f, i].data_ptr() for f in range(T) for i in range(6)])
+    check(lib().phnet_clip_loss(P, G, _ptr(tgt), T, n, L, w - 6, float(img_w), float(img_h), float(cls_w), float(reg_w),
+                                float(iou_w), float(liou_hw), float(liou_h), float(liou_w), _ptr(loss), D, _ptr(dgate),
+                                _ptr(rows), _ptr(srt), _ptr(scratch), _ptr(scratch[T * 6 * n:]), _stream()), "phnet_clip_loss")
+    return loss, dpred, dgate, rows, srt
+
+
 def lane_update_fwd(priors, head, ys, img_w, img_h):
     """priors [N,6+S], head [N,HW] -> (preds, lines) [N,6+S]."""
     _req(priors, name="priors"); _req(head, name="head")

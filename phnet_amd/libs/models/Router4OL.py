@@ -581,6 +581,18 @@ class RouterOL(nn.Module):
         pred, _ = det._branch(feat, pri, True)
         return pred
 
+    def _clip_loss(self, per_frame, lanes):
+        """Criterion over the frames of a clip whose predictions are all there (stage-major / wavefront schedules): one call when
+        the criterion offers `clip_loss` (loss4OLV3: two launches for the clip), else the reference's loop (trainOLV3.py:150-171)."""
+        outs = [{"predictions_fir": fr["predictions_fir"], "predictions_sec": fr["predictions_sec"]} for fr in per_frame]
+        if hasattr(self.criterion, "clip_loss"):
+            return self.criterion.clip_loss(outs, lanes, [fr["gates"] for fr in per_frame])
+        total_loss = 0.0
+        for t, out in enumerate(outs):
+            _, frame_loss = self.criterion(out, lanes[t:t + 1], per_frame[t]["gates"])
+            total_loss = total_loss + frame_loss
+        return total_loss
+
     def train_clip_stage_major(self, frame: torch.Tensor, lanes: torch.Tensor):
         """Training forward of one clip in STAGE-major order.  What ties the frames of a clip together is only branch B's
         memory: stage s of frame t attends to the stage-s tokens of the up to `save_freq_max` frames before it
@@ -658,12 +670,7 @@ class RouterOL(nn.Module):
             for s_ in range(S):
                 for t in range(T):
                     per_frame[t]["predictions_sec"].append(pb[s_ * T + t])
-        total_loss = 0.0
-        for t in range(T):
-            out = {"predictions_fir": per_frame[t]["predictions_fir"], "predictions_sec": per_frame[t]["predictions_sec"]}
-            _, frame_loss = self.criterion(out, lanes[t:t + 1], per_frame[t]["gates"])
-            total_loss = total_loss + frame_loss
-        return total_loss
+        return self._clip_loss(per_frame, lanes)
 
     def train_clip_wavefront(self, frame: torch.Tensor, lanes: torch.Tensor):
         """Training forward of one clip as a WAVEFRONT over (frame t, stage s).  (t, s) depends on (t, s-1) - its priors are
@@ -739,12 +746,7 @@ class RouterOL(nn.Module):
                 per_frame[t]["predictions_fir"][s] = fronts[i]["pred_a"]
                 per_frame[t]["predictions_sec"][s] = pb[i]
                 per_frame[t]["gates"][s] = fronts[i]["gate"]
-        total_loss = 0.0
-        for t in range(T):
-            out = {"predictions_fir": per_frame[t]["predictions_fir"], "predictions_sec": per_frame[t]["predictions_sec"]}
-            _, frame_loss = self.criterion(out, lanes[t:t + 1], per_frame[t]["gates"])
-            total_loss = total_loss + frame_loss
-        return total_loss
+        return self._clip_loss(per_frame, lanes)
 
     def lanes_from_device(self, kept_rows: torch.Tensor, nums: torch.Tensor):
         """One device->host copy per clip, then the host-side Lane construction (Router4OL.py:394-435)."""

@@ -7,6 +7,8 @@ Sync-free and shape-static: the label assignment (cost matrix + exact matching) 
 anchors come back as a fixed-size device vector padded with -1.  Nothing in the criterion reads a device value on the
 host, so a whole training step can be captured in a hipGraph.  The focal / smooth-L1 / LaneIoU arithmetic is still
 expressed as device tensor ops."""
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -36,6 +38,33 @@ class _FusedFrameLoss(torch.autograd.Function):
         return (None, None, *[dp[i].view(ctx.pshape) for i in range(6)], *[dg[i].view(ctx.gshape) for i in range(3)])
 
 
+class _FusedClipLoss(torch.autograd.Function):
+    """T frames x (6 predictions, 3 gates) -> (frame losses [T], matched rows [T,6,L]): phnet_clip_loss, two launches for the whole
+    clip; the upstream gradients scale all of its gradients in two launches."""
+
+    @staticmethod
+    def forward(ctx, crit, tgt, T, *tensors):
+        per = [tensors[9 * t:9 * t + 9] for t in range(T)]
+        preds = [[x.reshape(-1, x.shape[-1]).contiguous() for x in fr[:6]] for fr in per]
+        gates = [[x.reshape(-1).contiguous() for x in fr[6:]] for fr in per]
+        loss, dpred, dgate, _, rows_sorted = K.clip_loss(
+            preds, gates, tgt.contiguous(), crit.img_w, crit.img_h, crit.cls_weight, crit.reg_weight, crit.iou_weight,
+            crit.liou_half_width, crit.liou_img_h, crit.liou_img_w)
+        ctx.save_for_backward(dpred, dgate)
+        ctx.T, ctx.pshape, ctx.gshape = T, tensors[0].shape, tensors[6].shape
+        ctx.mark_non_differentiable(rows_sorted)
+        return loss, rows_sorted
+
+    @staticmethod
+    def backward(ctx, gloss, _rows):
+        dpred, dgate = ctx.saved_tensors
+        dp, dg = dpred * gloss.view(-1, 1, 1, 1), dgate * gloss.view(-1, 1, 1)
+        out = []
+        for t in range(ctx.T):
+            out += [dp[t, i].view(ctx.pshape) for i in range(6)] + [dg[t, i].view(ctx.gshape) for i in range(3)]
+        return (None, None, None, *out)
+
+
 class Criterion4OL(nn.Module):
     def __init__(self, cfg):
         super().__init__()
@@ -48,6 +77,8 @@ class Criterion4OL(nn.Module):
         self.liou_half_width, self.liou_img_h, self.liou_img_w = 7.5 / 768, 400, 960
         self._consts = {}
         self.fused = True          # phnet_frame_loss (2 launches / frame); False -> tensor-op spelling
+        self.frame_observer = None # callable(output, gt_lane, diff, matched, loss) per frame of a clip_loss call
+        self.clip_fused = os.environ.get("PHNET_CLIP_LOSS", "1") != "0"     # clip_loss: the frames of a clip in one pair of launches (A/B switch)
 
     def _const(self, key, values, like):
         k = (key, like.device)
@@ -122,6 +153,29 @@ class Criterion4OL(nn.Module):
         cls = torch.sum((1 - d) * (cls_a - delta / 2) + d * (cls_b + delta / 2))
         total = (reg_a + reg_b) * self.reg_weight + (iou_a + iou_b) * self.iou_weight + cls * self.cls_weight
         return matched_b, total
+
+    def clip_loss(self, outputs, gt_lanes, diffs):
+        """Sum of `forward(outputs[t], gt_lanes[t:t+1], diffs[t])[1]` over the frames of a clip - the caller's loop of
+        trainOLV3.py:150-171 - in two launches when the fused kernels apply (this class's own criterion, <= 8 frames), else frame by
+        frame.  outputs: list over frames of {"predictions_fir": 3 x [1,N,6+S], "predictions_sec": 3 x ...}; gt_lanes [T,L,6+S];
+        diffs: list over frames of the 3 gate tensors."""
+        T = len(outputs)
+        fa, fb = outputs[0]["predictions_fir"], outputs[0]["predictions_sec"]
+        own = type(self).loss4OneStep is Criterion4OL.loss4OneStep
+        if (own and self.fused and self.clip_fused and 1 <= T <= 8 and len(fa) == 3 and len(fb) == 3 and gt_lanes.shape[1] <= 4 and fa[0].shape[-2] <= 256
+                and fa[0].is_cuda and fa[0].shape[0] == 1):
+            flat = []
+            for t in range(T):
+                flat += [*outputs[t]["predictions_fir"], *outputs[t]["predictions_sec"], *diffs[t]]
+            loss, rows = _FusedClipLoss.apply(self, gt_lanes, T, *flat)
+            if self.frame_observer is not None:            # what a per-frame call would have returned (tests, logging)
+                for t in range(T):
+                    self.frame_observer(outputs[t], gt_lanes[t:t + 1], diffs[t], [rows[t, 3], rows[t, 4], rows[t, 5]], loss[t])
+            return loss.sum()
+        total = 0.0
+        for t in range(T):
+            total = total + self(outputs[t], gt_lanes[t:t + 1], diffs[t])[1]
+        return total
 
     def forward(self, output, gt_lane, diff=None):
         """-> (matched anchors of branch B per stage: i64[L] ascending, padded with -1; scalar loss).

@@ -141,15 +141,11 @@ def gpu_two_rank_step_vs_pair_fixture(rank, world):
     frames = synth.make_clip(g, T, seed=3407 + rank).cuda()
     lanes = synth.make_targets(g, T).cuda()
     rec = {"matched": [], "loss": []}
-    crit = model.criterion
-    crit_fwd = crit.forward
 
-    def hook(o, gt, diff=None):
-        m, l = crit_fwd(o, gt, diff)
+    def record(o, gt, diff, m, l):
         rec["matched"].append([[i for i in x.cpu().tolist() if i >= 0] for x in m])
         rec["loss"].append(float(l.detach()))
-        return m, l
-    crit.forward = hook
+    undo = synth.observe_criterion(model.criterion, record)
     opt, arena = FlatAdamW.for_model(model, lr=0.0, weight_decay=0.0)                 # lr 0: the step leaves the weights alone
     reducer = parallel.BucketReducer(arena.flat, arena.bucket_bounds)
     parts, n_coll = [], [0]
@@ -159,7 +155,7 @@ def gpu_two_rank_step_vs_pair_fixture(rank, world):
     finally:
         parallel._RUNNER = None
     torch.cuda.synchronize()
-    crit.forward = crit_fwd
+    undo()
     names = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "grad_names_resnet18.json")))
     params = dict(model.named_parameters())
     return {"loss": float(loss), "frame_loss": rec["loss"], "matched": rec["matched"], "parts": parts, "collectives": n_coll[0],
@@ -185,15 +181,11 @@ def gpu_two_ranks_two_clips_each_vs_quad_fixture(rank, world):
     frames = torch.stack([synth.make_clip(g, T, seed=s) for s in seeds]).cuda()
     lanes = torch.stack([synth.make_targets(g, T)] * B).cuda()
     rec = {"matched": [], "loss": []}
-    crit = model.criterion
-    crit_fwd = crit.forward
 
-    def hook(o, gt, diff=None):
-        m, l = crit_fwd(o, gt, diff)
+    def record(o, gt, diff, m, l):
         rec["matched"].append([[i for i in x.cpu().tolist() if i >= 0] for x in m])
         rec["loss"].append(float(l.detach()))
-        return m, l
-    crit.forward = hook
+    undo = synth.observe_criterion(model.criterion, record)
     opt, arena = FlatAdamW.for_model(model, lr=0.0, weight_decay=0.0)
     reducer = parallel.BucketReducer(arena.flat, arena.bucket_bounds)
     n_coll = [0]
@@ -203,7 +195,7 @@ def gpu_two_ranks_two_clips_each_vs_quad_fixture(rank, world):
     finally:
         parallel._RUNNER = None
     torch.cuda.synchronize()
-    crit.forward = crit_fwd
+    undo()
     names = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "grad_names_resnet18.json")))
     params = dict(model.named_parameters())
     return {"loss": float(loss), "frame_loss": rec["loss"], "matched": rec["matched"], "collectives": n_coll[0],

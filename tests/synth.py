@@ -336,3 +336,21 @@ def make_state_v2(g: "O2.GeometryV2") -> "OrderedDict[str, torch.Tensor]":
     sd["router.priors_on_featmap"] = on_map.clone()
     sd["router.PositionEmbedding.pos_table"] = O2.positional_table(g.num_priors, g.hidden)
     return OrderedDict((k, sd[k]) for k in spec)
+
+
+def observe_criterion(crit, record):
+    """record(output, gt_lane, diff, matched, loss) for every frame the criterion sees, whichever entry the schedule uses (one call
+    per frame, or `clip_loss` for the frames of a clip at once).  Returns undo()."""
+    fwd = crit.forward
+
+    def hook(o, gt, diff=None):
+        m, l = fwd(o, gt, diff)
+        record(o, gt, diff, m, l)
+        return m, l
+    crit.forward = hook
+    crit.frame_observer = record
+
+    def undo():
+        crit.forward = fwd
+        crit.frame_observer = None
+    return undo

@@ -92,22 +92,17 @@ def _close_lines(a, b, what="", cascade=False):
 
 
 def _record_heads(model):
-    """Per-frame head outputs as the criterion receives them (it is called once per frame, in frame order, by every training
-    schedule - frame-major and stage-major alike)."""
+    """Per-frame head outputs as the criterion receives them, in frame order (one call per frame in the frame-major schedule,
+    `clip_loss` over the frames of a clip in the stage-major one: synth.observe_criterion sees both)."""
     rec = {"fir": [], "sec": [], "gate": [], "matched": [], "frame_loss": []}
-    crit = model.criterion
-    crit_fwd = crit.forward
 
-    def crit_hook(o, gt, diff=None):
-        m, l = crit_fwd(o, gt, diff)
+    def record(o, gt, diff, m, l):
         rec["fir"].append(torch.stack([p.detach()[0] for p in o["predictions_fir"]]).cpu())
         rec["sec"].append(torch.stack([p.detach()[0] for p in o["predictions_sec"]]).cpu())
         rec["gate"].append(torch.stack([d.detach()[0, :, 0] for d in diff]).cpu())
         rec["matched"].append([np.asarray([i for i in x.cpu().tolist() if i >= 0], dtype=np.int64) for x in m])
         rec["frame_loss"].append(float(l.detach()))
-        return m, l
-    crit.forward = crit_hook
-    return rec, lambda: setattr(crit, "forward", crit_fwd)
+    return rec, synth.observe_criterion(model.criterion, record)
 
 
 def _train_case(g, T, gold_file, grad_names_file, grad_rtol=2e-2, grad_rms_atol=5e-3, counts=None, router_norm_rtol=5e-3):
@@ -712,21 +707,17 @@ def test_two_clips_per_step_equal_two_reference_ranks_with_syncbn():
     model = _build(g)
     model.train()
     rec = {"matched": [], "loss": []}
-    crit = model.criterion
-    crit_fwd = crit.forward
 
-    def hook(o, gt, diff=None):
-        m, l = crit_fwd(o, gt, diff)
+    def record(o, gt, diff, m, l):
         rec["matched"].append([[i for i in x.cpu().tolist() if i >= 0] for x in m])
         rec["loss"].append(float(l.detach()))
-        return m, l
-    crit.forward = hook
+    undo = synth.observe_criterion(model.criterion, record)
     frames = torch.stack([synth.make_clip(g, T, seed=s) for s in (3407, 3408)]).cuda()
     lanes = torch.stack([synth.make_targets(g, T)] * 2).cuda()
     loss = model({"frame": frames, "lanes": lanes})
     loss.backward()
     torch.cuda.synchronize()
-    crit.forward = crit_fwd
+    undo()
     assert abs(loss.item() - gold["pair_loss"]) <= ACT_TOL * abs(gold["pair_loss"])
     for t in range(T):                                       # the criterion is called clip by clip inside every frame index
         for b in range(2):
@@ -852,6 +843,58 @@ def test_fused_frame_loss_equals_tensor_op_criterion():
         for i, (t, gr) in enumerate(zip(preds + gates, ref_g)):
             scale = float(gr.abs().max()) + 1e-8
             assert float((t.grad - gr).abs().max()) <= 2e-4 * scale + 1e-7, (n_lanes, i, float((t.grad - gr).abs().max()), scale)
+
+
+def test_clip_loss_equals_the_frame_by_frame_criterion():
+    """Criterion4OL.clip_loss (phnet_clip_loss: the frames of a clip in two launches) against the caller's loop of the reference
+    (one criterion call per frame, losses added): same matched anchors, the same loss to the last bits of a 5-term sum, the same
+    gradients bit for bit (the same kernels run per frame; only the launch grid differs) - frames with 0, 1, 3 and 4 lanes."""
+    from phnet_amd.config import make_cfg
+    from phnet_amd.libs.utils.loss4OLV3 import Criterion4OL
+    g = O.Geometry()
+    crit = Criterion4OL(make_cfg())
+    r = np.random.default_rng(19)
+    pri, _ = O.priors_from_embeddings(O.initial_anchor_embeddings(g), g)
+    lanes_per_frame = (3, 4, 1, 0, 2)
+    T = len(lanes_per_frame)
+    tgt = torch.cat([synth.make_targets(g, 1, n_lanes=max(n, 1)) for n in lanes_per_frame], dim=0).cuda()
+    for t, n in enumerate(lanes_per_frame):
+        if n == 0:
+            tgt[t, :, :] = -1e5; tgt[t, :, 0] = 1; tgt[t, :, 1] = 0
+
+    def mk():
+        x = pri.clone()
+        x[:, :2] = torch.from_numpy(r.normal(0, 1, (240, 2)).astype(np.float32))
+        x[:, 2:5] += torch.from_numpy(r.normal(0, 0.02, (240, 3)).astype(np.float32))
+        x[:, 5] = torch.from_numpy(r.uniform(0.3, 0.9, 240).astype(np.float32))
+        x[:, 6:] += torch.from_numpy(r.normal(0, 0.01, (240, 36)).astype(np.float32))
+        return x.unsqueeze(0).cuda().requires_grad_(True)
+    outs, gates = [], []
+    for t in range(T):
+        preds = [mk() for _ in range(6)]
+        outs.append({"predictions_fir": preds[:3], "predictions_sec": preds[3:]})
+        gates.append([torch.from_numpy(r.uniform(0.5, 1.0, (1, 240, 1)).astype(np.float32)).cuda().requires_grad_(True) for _ in range(3)])
+    leaves = [x for t in range(T) for x in (*outs[t]["predictions_fir"], *outs[t]["predictions_sec"], *gates[t])]
+    total, matched = 0.0, []
+    for t in range(T):
+        m, l = crit(outs[t], tgt[t:t + 1], gates[t])
+        matched.append(m)
+        total = total + l
+    (total * 0.2).backward()
+    ref_g = [x.grad.clone() for x in leaves]
+    for x in leaves:
+        x.grad = None
+    loss = crit.clip_loss(outs, tgt, gates)
+    (loss * 0.2).backward()
+    assert abs(float(loss) - float(total)) <= 4e-7 * abs(float(total)), (float(loss), float(total))
+    for x, gr in zip(leaves, ref_g):
+        assert torch.equal(x.grad, gr)
+    # a criterion that overrides the per-frame entry (loss4OL / loss4OLV2) falls back to the loop
+    from phnet_amd.libs.utils.loss4OL import Criterion4OL as CritV1
+    c1 = CritV1(make_cfg())
+    l1 = c1.clip_loss(outs, tgt, gates)
+    want = sum(float(c1(outs[t], tgt[t:t + 1], gates[t])[1]) for t in range(T))
+    assert abs(float(l1) - want) <= 1e-5 * abs(want)
 
 
 @pytest.mark.parametrize("cfg", ["tiny", "config2"])
