@@ -295,7 +295,7 @@ def conv2d_wgrad(dy, x, w_shape, stride: int, pad: int, dw: Optional[torch.Tenso
     taps3 = (_MMA_MODE == 3 and r == 3 and s == 3 and stride == 1 and pad == 1 and ci % 64 == 0 and co % 64 == 0 and wi >= 16 and
              n * ho * wo >= 64 and _WGRAD3)                                              # three-taps kernel (csrc/conv.hip)
     _timed_launch(lambda: (f"linear_wgrad_smallp_kernel<64, 64, {1 if _MMA_MODE == 1 else 0}>" if smallp
-                           else "wgrad3s_kernel<1>" if taps3 and dbias is None and _WGRAD3S
+                           else "wgrad3s_kernel<2>" if taps3 and dbias is None and _WGRAD3S
                            else "conv_wgrad3x3_kernel<4, 16>" if taps3
                            else f"conv_wgrad_kernel<{128 if (co >= 128 and (co < 256 or n * ho * wo > 8192)) else 64}, 64, {_MMA_MODE}, 16, {4 if _MMA_MODE == 3 else 1}, {'true' if _MMA_MODE == 3 else 'false'}>", 0),
                   2.0 * n * ho * wo * co * r * s * ci,

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-3 evidence run on the GPU box (one gpurun call): kernel stats + (kernel, grid) distribution of the bench command,
 # PMC HBM-traffic passes of the bench, MFMA-pipe utilisation of the trunk GEMMs AS THE TRUNK SCHEDULE RUNS THEM (forward / dgrad
-# on packed weights: conv3p_kernel; weight gradient: conv_wgrad3x3_kernel), the 8(f) rows.  Summaries land in gpurun_out/final/
+# on packed weights: conv3p_kernel; weight gradient: wgrad3s_kernel), the 8(f) rows.  Summaries land in gpurun_out/final/
 # (copied into profiles/ by hand); raw traces are deleted.  The summary records the sha256 of the kernel sources it was taken on.
 # usage: r03_profiles.sh [tag]
 set -e -o pipefail
@@ -29,13 +29,13 @@ sys.path.insert(0, "$R/tests/tools")
 from kernel_sha import kernel_sources_sha
 t = json.load(open("$O/${TAG}_pmc_traffic.json"))
 m = json.load(open("$O/${TAG}_pmc_mfma_trunk.json"))
-rows = {k: v["mfma_util_pct"] for k, v in m.items() if k.startswith("conv3p_kernel") or k.startswith("conv_wgrad3x3")}
+rows = {k: v["mfma_util_pct"] for k, v in m.items() if k.startswith("conv3p_kernel") or k.startswith("conv_wgrad3x3") or k.startswith("wgrad3s_kernel")}
 vals = list(rows.values())
 json.dump({"kernel_sources_sha256": kernel_sources_sha("$R"), "traffic": t,
            "backbone_conv_mfma_util": {"min": min(vals), "max": max(vals), "rows": rows, "arithmetic": "bf16x3",
                                        "source": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE on tests/tools/bench_conv.py --quick --trunk --mode 3 --packed "
                                                  "(ResNet-34 stage convs of a 5x320x800 clip as the trunk schedule runs them: forward + dgrad = conv3p_kernel on packed "
-                                                 "weights, weight gradient = conv_wgrad3x3_kernel), profiles/${TAG}_pmc_mfma_trunk.json; busy cycles of the bf16 matrix "
+                                                 "weights, weight gradient = wgrad3s_kernel), profiles/${TAG}_pmc_mfma_trunk.json; busy cycles of the bf16 matrix "
                                                  "pipe / (kernel cycles x 1024 SIMDs)"}},
           open("$O/${TAG}_pmc_summary.json", "w"), indent=1)
 PY
