@@ -1763,7 +1763,7 @@ PHNET_API int phnet_conv2d_wgrad(const float* dy, const float* x, float* dw, flo
         long splits = wgrad3_splits(P, Co, Ci);
         const long row = (long)Co * NC + Co;
         while (splits > 1 && (!workspace || (uint64_t)(splits * row * sizeof(float)) > ws_bytes)) --splits;
-        const bool pc = g_wgrad3s && !dbias;                      // producer / consumer kernel
+        const bool pc = g_wgrad3s && !dbias && (long)Hi * Wi >= phnet_wgrad3s_kstep();      // producer / consumer kernel (an image holds >= one K step)
         const int bkw = pc ? phnet_wgrad3s_kstep() : g_wgrad3_bkw == 16 ? 16 : 32;
         const long psteps = ceil_div64(P, bkw);
         g.splits = (int)splits;

@@ -299,7 +299,7 @@ def test_packed_weight_3x3_kernel_vs_fp64(ops, bf16x3, case):
 
 
 @pytest.mark.parametrize("case", [(2, 16, 20, 64, 64), (3, 5, 17, 64, 128), (2, 7, 16, 128, 64), (1, 1, 70, 64, 64), (5, 20, 50, 256, 64),
-                                  (1, 10, 25, 512, 512), (4, 3, 23, 64, 64)])
+                                  (1, 10, 25, 512, 512), (4, 3, 23, 64, 64), (4, 1, 20, 64, 64), (3, 2, 16, 64, 64)])
 def test_wgrad_three_taps_kernel_vs_fp64(ops, bf16x3, case):
     """conv_wgrad3x3_kernel (3x3 / stride 1 / pad 1, the three taps of a filter row from one staged pixel block): image rows
     narrower / wider than the 16-pixel block, blocks that span image rows and frames, one-row images (every row is the top and

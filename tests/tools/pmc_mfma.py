@@ -13,7 +13,7 @@ for path in glob.glob(sys.argv[1]):
         rows[(r["Dispatch_Id"], short(r["Kernel_Name"]), r["Grid_Size"])][r["Counter_Name"]] = float(r["Counter_Value"])
 agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
 for (_, k, grid), c in rows.items():
-    if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c and k.startswith("conv"):
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c and (k.startswith("conv") or k.startswith("wgrad")):
         a = agg[f"{k} grid={grid}"]
         a[0] += 1; a[1] += c["SQ_VALU_MFMA_BUSY_CYCLES"]; a[2] += c["GRBM_GUI_ACTIVE"]
 out = {}
