@@ -136,7 +136,7 @@ class DetNetV2(nn.Module):
             if zero_head is None or zero_head.device != emb.device:
                 zero_head = self._zero_head = torch.zeros((1, self.num_priors, 6 + S), dtype=torch.float32, device=emb.device)
             pri0 = torch.nn.functional.pad(emb, (2, 1 + S)).unsqueeze(0)                 # [1,N,6+S]: (0, 0, sy, sx, theta, 0, 0...)
-            pri = PF.lane_update(pri0, zero_head, self.prior_ys, self.img_w, self.img_h)[1][0]
+            pri = PF.lane_update(pri0, zero_head, self.prior_ys, self.img_w, self.img_h)[1].squeeze(0)
             return pri, pri[:, 6 + self.sample_x_indexs]
         sy, sx, theta = emb.split(1, dim=1)                              # (module construction on the host: plain tensor ops)
         xs = self._line_xs(sy, sx, theta)
@@ -374,6 +374,11 @@ class DetNetV2(nn.Module):
 BRANCH_B_SITES = 1 << 10      # dropout site numbering of branch B inside DropoutStream.items (functional.py)
 
 
+class _Stacked(list):
+    """The per-stage token rings (or their validity masks) as a list, with the one tensor they are views of in `.stacked`."""
+    stacked = None
+
+
 class _BranchBDeferred(torch.autograd.Function):
     """Backward of ALL branch-B passes of a clip as ONE batch.
 
@@ -569,8 +574,11 @@ class RouterOL(nn.Module):
             L1 = rings[0].shape[1]
             tokv = tok.view(S, T, N, E)
             tgt = tokv[:, 1:].reshape(S * (T - 1) * N, E)
-            ring = torch.stack(rings) if S > 1 else rings[0].unsqueeze(0)                        # [S,W+T,L1,E]
-            valid = torch.stack(valids) if S > 1 else valids[0].unsqueeze(0)
+            ring = getattr(rings, "stacked", None)                                              # [S,W+T,L1,E]
+            valid = getattr(valids, "stacked", None)
+            if ring is None or valid is None or ring.shape[0] != S:
+                ring = torch.stack(rings) if S > 1 else rings[0].unsqueeze(0)
+                valid = torch.stack(valids) if S > 1 else valids[0].unsqueeze(0)
             st = ring.stride()
             mem = ring.as_strided((S, T - 1, W * L1, E), (st[0], st[1], E, 1), ring.storage_offset() + st[1]).reshape(-1, E)
             sv = valid.stride()
@@ -620,15 +628,18 @@ class RouterOL(nn.Module):
         det._branch_weights(True)                                              # assembled WITH autograd, before any no_grad use
         per_frame = [{"predictions_fir": [], "predictions_sec": [], "gates": []} for _ in range(T)]
         pos = det.PositionEmbedding.embed.weight.unsqueeze(0).expand(T, -1, -1)
-        tokens, rings, valids, pre_pred, pri_used = [], [], [], [], []
+        tokens, rings, valids, pre_pred, pri_used = [], _Stacked(), _Stacked(), [], []
         pri0 = priors
+        # the token rings of all stages in ONE zero-filled allocation each (2 fills per clip instead of 2 per stage, and the batched
+        # backward finds them stacked already)
+        rings.stacked = torch.zeros((S, W + T, L1, E), dtype=torch.float32, device=dev)
+        valids.stacked = torch.zeros((S, W + T, L1), dtype=torch.bool, device=dev)
         for stage in range(S):
             front = det.stage_front(levels[stage], stage, priors, on_map, pro)                 # everything [T,...]
             attn_all = torch.cat([front["local"], pos], dim=-1)                               # branch B's input of all frames [T,N,E]
             # memory tokens of this stage: a ring with W leading slots that are never valid - frame t's window is ALWAYS
             # ring[t : t + W] (fixed key positions: the batched backward sees the keys where the forward saw them)
-            ring = torch.zeros((W + T, L1, E), dtype=torch.float32, device=dev)
-            ring_valid = torch.zeros((W + T, L1), dtype=torch.bool, device=dev)
+            ring, ring_valid = rings.stacked[stage], valids.stacked[stage]
             if defer:
                 src, pri_src = attn_all.detach(), priors.detach()
             else:

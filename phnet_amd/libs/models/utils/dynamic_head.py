@@ -39,7 +39,7 @@ class DynamicConv(nn.Module):
         if name not in self._folded:
             l1, l2 = seq[0], seq[1]
             w_eff_t = PF.linear(l1.weight.t().contiguous(), l2.weight)              # [K, N] = (W2 W1)^T
-            b_eff = PF.linear(l1.bias.unsqueeze(0), l2.weight, l2.bias)[0]          # W2 b1 + b2
+            b_eff = PF.linear(l1.bias.unsqueeze(0), l2.weight, l2.bias).view(-1)    # W2 b1 + b2 (a view: `[0]` costs a zero-fill + copy in the backward)
             self._folded[name] = (grad_sink(w_eff_t.t().contiguous(), self._sink_pool), grad_sink(b_eff.contiguous(), self._sink_pool))
         return self._folded[name]
 
