@@ -18,7 +18,8 @@ int phnet_tune_force_k_tile(int32_t k_tile);   /* 0 = heuristic, else 16 | 32 | 
 int phnet_tune_wgrad(int32_t allow_bm128, int32_t target_blocks);   /* wgrad tile / split-K policy; bits of the first argument:
                                                                         1 = no few-rows Linear kernel, 3 = no three-taps 3x3 kernel,
                                                                         4 = its 32-pixel steps, 5 = no producer / consumer variant
-                                                                        (csrc/wgrad3s.hip); a NEGATIVE second argument sets the
+                                                                        (csrc/wgrad3s.hip), 6 = no 128 x 128 producer / consumer Linear
+                                                                        kernel (csrc/wgrad1s.hip); a NEGATIVE second argument sets the
                                                                         three-taps kernel's workgroup target (default 256) */
 /* arithmetic of the GEMM kernels: 3 = exact three-term bf16 split staged in LDS (library default), 0 = f32-input MFMA,
  * 1 = two-term bf16 split in registers (3 MFMAs per product, ~2^-16 per product), 2 = three-term split in registers */

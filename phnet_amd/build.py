@@ -12,7 +12,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hi
 # per-source additions.  SLP packs adjacent f32 adds into v_pk_add_f32, which costs more issue time beside MFMAs than the two plain adds
 # it replaces (MI355X_MICROARCH.md): the producer waves of wgrad3s.hip share their SIMDs with MFMA streams (50 -> 44 us per launch);
 # measured on the other GEMM sources: -5 % (their split arithmetic sits in the MFMA waves themselves), so only there
-EXTRA_FLAGS = {"wgrad3s.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"wgrad3s.hip": ["-fno-slp-vectorize"], "wgrad1s.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc():

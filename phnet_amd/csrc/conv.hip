@@ -999,6 +999,7 @@ constexpr int W3_THREADS = 768;
 int g_wgrad3 = 1, g_wgrad3_target = 256;                     // tuning aids (phnet_tune_wgrad: bit 3 of arg 0 switches it off; a negative
 int g_wgrad3_bkw = 16;                                       // second argument sets its workgroup target, bit 4 selects 32-pixel steps)
 int g_wgrad3s = 1;                                           // producer / consumer variant (csrc/wgrad3s.hip) where no bias gradient is asked for; bit 5 switches it off
+int g_wgrad1s = 1;                                           // 128 x 128 producer / consumer kernel for many-row Linear layers (csrc/wgrad1s.hip); bit 6 switches it off
 template <int BKW> struct Wgrad3Lds {
     static constexpr int ROWS = BKW + 2;                     // X rows of a step: pixels pt-1 .. pt+BKW of the shifted image row
     static constexpr int PITCH = KStridedPlanes<64, BK>::PITCH;      // 192 bytes: 64 bf16 + pad (igemm.h)
@@ -1571,6 +1572,7 @@ PHNET_API int phnet_tune_wgrad(int32_t allow_bm128, int32_t target_blocks)
     g_wgrad3 = !(allow_bm128 & 8);
     g_wgrad3_bkw = (allow_bm128 & 16) ? 32 : 16;
     g_wgrad3s = !(allow_bm128 & 32);
+    g_wgrad1s = !(allow_bm128 & 64);
     if (target_blocks < 0) g_wgrad3_target = -target_blocks;      // workgroup target of the three-taps 3x3 kernel
     else g_wgrad_target = target_blocks;
     return PHNET_OK;
@@ -1796,6 +1798,24 @@ PHNET_API int phnet_conv2d_wgrad(const float* dy, const float* x, float* dw, flo
             const long nw = (long)Co * NC, nb = Co;
             hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div64((nw + nb) >> 2, 64)), dim3(256), 0, st,
                                (const float*)workspace, dw, dbias, nw, nb, (int)splits, accumulate);
+        }
+        return phnet_launch_status();
+    }
+    // Linear / 1x1 layers over many rows with >= 64 tiles of 128 x 128: the producer / consumer kernel (csrc/wgrad1s.hip)
+    if (g_wgrad1s && g_mma_mode == 3 && R == 1 && S == 1 && stride == 1 && pad == 0 && (Co & 127) == 0 && (Ci & 127) == 0 && P >= 256 &&
+        (long)(Co / 128) * (Ci / 128) >= 64 && P * (long)max(Ci, Co) * 4 < 0x7fffffffL) {
+        const long tiles1 = (long)(Co / 128) * (Ci / 128);
+        long splits1 = max((long)1, min((long)(P / 128), (long)256 / tiles1));
+        const long row = (long)Co * NC + Co;
+        while (splits1 > 1 && (!workspace || (uint64_t)(splits1 * row * sizeof(float)) > ws_bytes)) --splits1;
+        const int ks = phnet_wgrad1s_kstep();
+        Wgrad1sShape s1{(int)P, Ci, Co, (int)splits1, (int)(ceil_div64(ceil_div64(P, ks), splits1) * ks)};
+        const int rc = phnet_wgrad1s_launch(dy, x, splits1 > 1 ? (float*)workspace : dw, dbias, s1, accumulate, st);
+        if (rc != PHNET_OK) return rc;
+        if (splits1 > 1) {
+            const long nw = (long)Co * NC, nb = Co;
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div64((nw + nb) >> 2, 64)), dim3(256), 0, st,
+                               (const float*)workspace, dw, dbias, nw, nb, (int)splits1, accumulate);
         }
         return phnet_launch_status();
     }

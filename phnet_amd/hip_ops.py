@@ -275,6 +275,7 @@ def conv2d_dgrad(dy, w, in_hw: Tuple[int, int], stride: int, pad: int, addend: O
 CONV3P = os.environ.get("PHNET_CONV3P", "1") != "0"           # packed-weight 3x3 kernel for the trunk / FPN forward and data gradient (trunk.packed_path); bench A/B switch
 _WGRAD3 = True          # mirrors csrc/conv.hip g_wgrad3 (kernel names of the bench's per-kernel accounting only)
 _WGRAD3S = True         # mirrors g_wgrad3s (same purpose)
+_WGRAD1S = True         # mirrors g_wgrad1s
 
 
 def conv2d_wgrad(dy, x, w_shape, stride: int, pad: int, dw: Optional[torch.Tensor] = None, accumulate: bool = False,
@@ -295,6 +296,8 @@ def conv2d_wgrad(dy, x, w_shape, stride: int, pad: int, dw: Optional[torch.Tenso
     taps3 = (_MMA_MODE == 3 and r == 3 and s == 3 and stride == 1 and pad == 1 and ci % 64 == 0 and co % 64 == 0 and wi >= 16 and
              n * ho * wo >= 64 and _WGRAD3)                                              # three-taps kernel (csrc/conv.hip)
     _timed_launch(lambda: (f"linear_wgrad_smallp_kernel<64, 64, {1 if _MMA_MODE == 1 else 0}>" if smallp
+                           else "wgrad1s_kernel" if (_WGRAD1S and _MMA_MODE == 3 and r == 1 and s == 1 and stride == 1 and pad == 0 and co % 128 == 0
+                                                     and ci % 128 == 0 and n * ho * wo >= 256 and (co // 128) * (ci // 128) >= 64)
                            else "wgrad3s_kernel<2>" if taps3 and dbias is None and _WGRAD3S
                            else "conv_wgrad3x3_kernel<4, 16>" if taps3
                            else f"conv_wgrad_kernel<{128 if (co >= 128 and (co < 256 or n * ho * wo > 8192)) else 64}, 64, {_MMA_MODE}, 16, {4 if _MMA_MODE == 3 else 1}, {'true' if _MMA_MODE == 3 else 'false'}>", 0),
@@ -1110,10 +1113,11 @@ def tune_k_tile(code: int) -> None:
 def tune_wgrad(flags: int = 1, target: int = 768) -> None:
     """Benchmark aid (process-global): phnet_tune_wgrad - bit 3 of `flags` switches the three-taps 3x3 weight-gradient kernel off,
     bit 4 gives it 32-pixel steps, bit 5 switches its producer / consumer variant (csrc/wgrad3s.hip) off; a negative `target` is ITS workgroup target, a positive one the generic kernel's."""
-    global _WGRAD3, _WGRAD3S
+    global _WGRAD3, _WGRAD3S, _WGRAD1S
     check(lib().phnet_tune_wgrad(flags, target), "phnet_tune_wgrad")
     _WGRAD3 = not (flags & 8)
     _WGRAD3S = not (flags & 32)
+    _WGRAD1S = not (flags & 64)
 
 
 def set_mma_mode(mode: str) -> None:

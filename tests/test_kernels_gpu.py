@@ -298,6 +298,37 @@ def test_packed_weight_3x3_kernel_vs_fp64(ops, bf16x3, case):
     close(ops.conv3p(gyd, pd, Ci, dgrad=True), ops.conv2d_dgrad(gyd, wd, (Hi, Wi), 1, 1).double().cpu(), 2e-5)
 
 
+@pytest.mark.parametrize("case", [(1200, 1024, 1024), (257, 1152, 1024), (300, 1024, 1152), (1200, 2048, 512)])
+def test_many_row_linear_weight_gradient_kernel_vs_fp64(ops, bf16x3, case):
+    """wgrad1s_kernel (csrc/wgrad1s.hip: 128 x 128 tiles, 8 consumer + 4 producer waves) - the weight and bias gradient of a Linear
+    layer over many rows: ragged row counts (a last step of one row), overwrite and accumulate, with and without the bias
+    gradient, against fp64 and against the generic kernel (phnet_tune_wgrad bit 6 switches this one off)."""
+    from phnet_amd._lib import lib
+    P, Ci, Co = case
+    torch.manual_seed(P + Ci + Co)
+    x = torch.randn(P, Ci, dtype=torch.float64)
+    gy = torch.randn(P, Co, dtype=torch.float64)
+    want, want_b = gy.t() @ x, gy.sum(0)
+    xd, gyd = x.float().cuda().view(P, 1, 1, Ci), gy.float().cuda().view(P, 1, 1, Co)
+    shape = (Co, 1, 1, Ci)
+    db = torch.full((Co,), 7.0, device="cuda")
+    dw = ops.conv2d_wgrad(gyd, xd, shape, 1, 0, dbias=db)
+    close(dw.view(Co, Ci), want, 2e-5)
+    close(db, want_b, 2e-5)
+    ops.conv2d_wgrad(gyd, xd, shape, 1, 0, dw=dw, dbias=db, accumulate=True)
+    close(dw.view(Co, Ci), 2 * want, 2e-5)
+    close(db, 2 * want_b, 2e-5)
+    dw_nb = ops.conv2d_wgrad(gyd, xd, shape, 1, 0)
+    close(dw_nb.view(Co, Ci), want, 2e-5)
+    assert lib().phnet_tune_wgrad(1 | 64, 768) == 0                      # the generic kernel on the same operands
+    try:
+        dw_generic = ops.conv2d_wgrad(gyd, xd, shape, 1, 0)
+    finally:
+        assert lib().phnet_tune_wgrad(1, 768) == 0
+    close(dw_generic.view(Co, Ci), want, 2e-5)
+    close(dw_nb, dw_generic, 1e-5)
+
+
 @pytest.mark.parametrize("case", [(2, 16, 20, 64, 64), (3, 5, 17, 64, 128), (2, 7, 16, 128, 64), (1, 1, 70, 64, 64), (5, 20, 50, 256, 64),
                                   (1, 10, 25, 512, 512), (4, 3, 23, 64, 64), (4, 1, 20, 64, 64), (3, 2, 16, 64, 64)])
 def test_wgrad_three_taps_kernel_vs_fp64(ops, bf16x3, case):
