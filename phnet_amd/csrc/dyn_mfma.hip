@@ -66,6 +66,85 @@ __device__ __forceinline__ void product(const float* __restrict__ xn, const floa
     }
 }
 
+// one row fragment (rows 16 f .. 16 f + 15) of the same product, same order of operations per accumulator
+template <int K, int J>
+__device__ __forceinline__ void product_frag(const float* __restrict__ xn, const float* __restrict__ wn, int P, int lane, int f, f32x4 (&acc)[J / 16])
+{
+    constexpr int KS = K / 4, FN = J / 16, G2 = J / 64;
+    const int jj = lane & 15, kk = lane >> 4;
+    float a[KS];
+    {
+        const int row = 16 * f + jj;
+        const bool ok = row < P;
+        const f32x4* src = reinterpret_cast<const f32x4*>(xn + (size_t)(ok ? row : 0) * K + KS * kk);
+#pragma unroll
+        for (int t = 0; t < KS / 4; ++t) {
+            const f32x4 v = src[t];
+            a[4 * t] = ok ? v.x : 0.f; a[4 * t + 1] = ok ? v.y : 0.f; a[4 * t + 2] = ok ? v.z : 0.f; a[4 * t + 3] = ok ? v.w : 0.f;
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < FN; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* wrow = wn + (size_t)(KS * kk) * J + 4 * jj;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        f32x4 b[G2];
+#pragma unroll
+        for (int g2 = 0; g2 < G2; ++g2) b[g2] = *reinterpret_cast<const f32x4*>(wrow + (size_t)s * J + 64 * g2);
+#pragma unroll
+        for (int g = 0; g < FN; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[g >> 2][g & 3], acc[g], 0, 0, 0);
+    }
+}
+
+// Forward with one wavefront per (anchor, 16-row fragment): a launch of the kernel below is 1200 wavefronts on 1024 SIMDs, each
+// streaming its anchor's 32 KB of weights with nothing else on its SIMD to hide the load latency (47 / 40 us for 39 MB: ~1 TB/s).
+// The rows of an anchor are independent up to the LayerNorm, which is per row: the three row fragments of an anchor go to three
+// wavefronts (the second and third read the anchor's weights from L2), 3600 wavefronts per launch, a third of the registers each.
+// Same arithmetic per accumulator, bit for bit.
+template <int K, int J>
+__global__ __launch_bounds__(256, 4) void dyn_mfma_fwd_rows_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                   float* __restrict__ y, float* __restrict__ stats, int N, int P, int NFR, float eps)
+{
+    constexpr int FN = J / 16, G2 = J / 64;
+    const int lane = threadIdx.x & 63;
+    const int job = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int n = job / NFR, f = job - n * NFR;
+    if (n >= N) return;
+    const int jj = lane & 15, kk = lane >> 4;
+    f32x4 acc[FN];
+    product_frag<K, J>(x + (size_t)n * P * K, w + (size_t)n * K * J, P, lane, f, acc);
+    f32x4 gam[G2], bet[G2];
+#pragma unroll
+    for (int g2 = 0; g2 < G2; ++g2) {
+        gam[g2] = *reinterpret_cast<const f32x4*>(gamma + 64 * g2 + 4 * jj);
+        bet[g2] = *reinterpret_cast<const f32x4*>(beta + 64 * g2 + 4 * jj);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int row = 16 * f + 4 * kk + e;
+        float s = 0.f;
+#pragma unroll
+        for (int g = 0; g < FN; ++g) s += acc[g][e];
+        const float mu = group16_sum(s) * (1.0f / (float)J);
+        float q = 0.f;
+#pragma unroll
+        for (int g = 0; g < FN; ++g) { const float d = acc[g][e] - mu; q += d * d; }
+        const float rs = 1.0f / sqrtf(group16_sum(q) * (1.0f / (float)J) + eps);
+        if (row < P) {
+            if (jj == 0 && stats) { stats[((size_t)n * P + row) * 2] = mu; stats[((size_t)n * P + row) * 2 + 1] = rs; }
+            float* dst = y + ((size_t)n * P + row) * J + 4 * jj;
+#pragma unroll
+            for (int g2 = 0; g2 < G2; ++g2) {
+                f32x4 o;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) o[t] = fmaxf((acc[4 * g2 + t][e] - mu) * rs * gam[g2][t] + bet[g2][t], 0.f);
+                *reinterpret_cast<f32x4*>(dst + 64 * g2) = o;
+            }
+        }
+    }
+}
+
 // 256 threads = 4 anchors per workgroup (no LDS, no barrier)
 template <int K, int J>
 __global__ __launch_bounds__(256, 2) void dyn_mfma_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
@@ -278,6 +357,8 @@ __global__ __launch_bounds__(256, 2) void dyn_mfma_bwd_kernel(const float* __res
 
 }  // namespace
 
+int g_dyn_rows = 1;             // forward: one wavefront per (anchor, row fragment); phnet_tune_dyn_mfma(2 | ...) switches it off
+
 PHNET_API int phnet_dyn_mfma_applies(int32_t P, int32_t K, int32_t J)
 {
     return P >= 1 && P <= 36 && ((K == 64 && J == 128) || (K == 128 && J == 64));
@@ -289,6 +370,13 @@ PHNET_API int phnet_dyn_mfma_fwd(const float* x, const float* w, const float* ga
 {
     if (N < 1 || !phnet_dyn_mfma_applies(P, K, J) || !x || !w || !gamma || !beta || !y) return PHNET_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
+    if (g_dyn_rows) {                                           // one wavefront per (anchor, row fragment)
+        const int nfr = (P + 15) / 16;
+        const dim3 grid((unsigned)(((long)N * nfr + 3) / 4));
+        if (K == 64) hipLaunchKernelGGL((dyn_mfma_fwd_rows_kernel<64, 128>), grid, dim3(256), 0, st, x, w, gamma, beta, y, stats, N, P, nfr, eps);
+        else hipLaunchKernelGGL((dyn_mfma_fwd_rows_kernel<128, 64>), grid, dim3(256), 0, st, x, w, gamma, beta, y, stats, N, P, nfr, eps);
+        return phnet_launch_status();
+    }
     const dim3 grid((unsigned)((N + 3) / 4));
     if (K == 64) hipLaunchKernelGGL((dyn_mfma_fwd_kernel<64, 128>), grid, dim3(256), 0, st, x, w, gamma, beta, y, stats, N, P, eps);
     else hipLaunchKernelGGL((dyn_mfma_fwd_kernel<128, 64>), grid, dim3(256), 0, st, x, w, gamma, beta, y, stats, N, P, eps);

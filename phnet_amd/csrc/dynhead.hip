@@ -266,7 +266,8 @@ extern "C" int phnet_dyn_mfma_fwd(const float* x, const float* w, const float* g
 extern "C" int phnet_dyn_mfma_bwd(const float* dy, const float* x, const float* w, const float* y, const float* stats, const float* gamma,
                                   float* dx, float* dw, float* lnpart, int32_t N, int32_t P, int32_t K, int32_t J, void* stream);
 static int g_dyn_mfma = 1;       // matrix-pipe forward (dyn_mfma.hip) where it applies; phnet_tune_dyn_mfma(0) = the LDS / FMA kernels
-PHNET_API int phnet_tune_dyn_mfma(int32_t on) { g_dyn_mfma = on != 0; return PHNET_OK; }
+extern int g_dyn_rows;           // (dyn_mfma.hip) its forward with one wavefront per (anchor, row fragment); bit 1 of the argument switches that off
+PHNET_API int phnet_tune_dyn_mfma(int32_t on) { g_dyn_mfma = (on & 1) != 0; g_dyn_rows = !(on & 2); return PHNET_OK; }
 
 // y[n] = relu(LayerNorm_J(x[n] @ w[n]) * gamma + beta);  x [N][P][K], w [N][K][J], y [N][P][J], stats [N][P][2]
 // (mean, rstd; may be NULL for inference).  P <= 36; (K, J) in {(64,128), (128,64), (32,64), (64,32)}.

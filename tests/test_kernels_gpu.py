@@ -681,7 +681,7 @@ def test_layernorm_fwd_bwd(ops, rows, L, relu, res):
         close(dres, r.grad, 1e-6)
 
 
-@pytest.mark.parametrize("N,P,K,J", [(240, 36, 64, 128), (240, 36, 128, 64), (7, 36, 32, 64), (3, 5, 64, 32)])
+@pytest.mark.parametrize("N,P,K,J", [(240, 36, 64, 128), (240, 36, 128, 64), (7, 36, 32, 64), (3, 5, 64, 32), (241, 20, 64, 128), (5, 16, 128, 64)])
 def test_dynamic_head_bmm_layernorm_relu(ops, N, P, K, J):
     """relu(LayerNorm(x[n] @ w[n])) per anchor (dynamic_head.py:40-51) vs an fp64 torch reference."""
     torch.manual_seed(N + K)
@@ -697,6 +697,15 @@ def test_dynamic_head_bmm_layernorm_relu(ops, N, P, K, J):
     close(yd, y, 2e-5)
     y_inf, none = ops.dyn_bmm_ln_relu_fwd(xd, wd, gd, bd, 1e-5, save_stats=False)
     assert none is None and torch.equal(y_inf, yd)
+    from phnet_amd._lib import lib
+    if lib().phnet_dyn_mfma_applies(P, K, J):
+        # matrix-pipe forward: one wavefront per (anchor, 16-row fragment) by default, per anchor with the switch - the same bits
+        assert lib().phnet_tune_dyn_mfma(3) == 0
+        try:
+            y_a, st_a = ops.dyn_bmm_ln_relu_fwd(xd, wd, gd, bd, 1e-5)
+        finally:
+            assert lib().phnet_tune_dyn_mfma(1) == 0
+        assert torch.equal(y_a, yd) and torch.equal(st_a, stats)
     dx, dw, dg, db = ops.dyn_bmm_ln_relu_bwd(dev(g.float()), xd, wd, yd, stats, gd, 1e-5)
     close(dx, x.grad, 5e-5); close(dw, w.grad, 5e-5); close(dg, ga.grad, 5e-5); close(db, be.grad, 5e-5)
     # accumulate mode adds to the destinations; dx may be skipped

@@ -12,6 +12,8 @@ from tests.tools.bench_conv import timeit
 def main():
     if "--generic" in sys.argv:
         assert lib().phnet_tune_dyn_mfma(0) == 0
+    if "--per-anchor" in sys.argv:                         # forward with one wavefront per anchor (all three row fragments)
+        assert lib().phnet_tune_dyn_mfma(3) == 0
     N, P = 1200, 36
     for k, j in ((64, 128), (128, 64)):
         x = torch.randn(N, P, k, device="cuda")
