@@ -30,7 +30,7 @@ int phnet_conv3p_tune(int32_t target_workgroups);
  * one-workgroup-per-plane kernels (csrc/gate.hip) */
 int phnet_tune_gate_wave(int32_t on);
 /* per-anchor products of the dynamic head: 1 = matrix-pipe kernels, one wavefront per anchor (csrc/dyn_mfma.hip, default where they
- * apply; forward: one wavefront per anchor AND 16-row fragment), 3 = the same with the forward's one-wavefront-per-anchor form,
+ * apply; forward: one wavefront per anchor AND 16-row fragment, backward: four per anchor), 3 = the one-wavefront-per-anchor forms of both,
  * 0 = the LDS / FMA kernels of csrc/dynhead.hip */
 int phnet_tune_dyn_mfma(int32_t on);
 

@@ -355,9 +355,174 @@ __global__ __launch_bounds__(256, 2) void dyn_mfma_bwd_kernel(const float* __res
     }
 }
 
+// ---- the same backward with FOUR wavefronts per anchor (one workgroup = one anchor) ----
+// One wavefront per anchor is 1200 wavefronts of 1056 dependent-ish MFMAs each on 1024 SIMDs, with nothing to hide a load behind.
+// Here waves 0-2 take one 16-row fragment each: product, LayerNorm / ReLU backward, dF rows into a workgroup-shared LDS image, and -
+// after the one barrier - dX of those rows; the weight gradient sums over ALL rows, so its K/16 row blocks go to the four waves
+// (one each at K = 64, two at K = 128), each reading the whole dF image; wave 3, idle before the barrier, folds the three
+// fragments' LayerNorm affine partials.  4800 wavefronts per launch, 328 MFMAs on the longest.
+template <int K, int J>
+__global__ __launch_bounds__(256, 4) void dyn_mfma_bwd_split_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                    const float* __restrict__ w, const float* __restrict__ y,
+                                                                    const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                                    float* __restrict__ dx, float* __restrict__ dw, float* __restrict__ lnpart,
+                                                                    int N, int P)
+{
+    constexpr int FN = J / 16, G2 = J / 64, FK = K / 16, JS = J / 4, PITCH = J + 4, ROWS = 48, FKW = FK / 4;
+    extern __shared__ float lds[];                              // dF [ROWS][PITCH], then the affine partials [3][2][J]
+    float* Fs = lds;
+    float* lp = lds + ROWS * PITCH;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = blockIdx.x;
+    const int jj = lane & 15, kk = lane >> 4;
+    const float* xn = x + (size_t)n * P * K;
+    const float* wn = w + (size_t)n * K * J;
+    const int nfr = (P + 15) >> 4;                              // row fragments that hold rows
+    if (wv < 3) {
+        const int f = wv;
+        f32x4 pw[G2], pb[G2];
+#pragma unroll
+        for (int g2 = 0; g2 < G2; ++g2) { pw[g2] = (f32x4){0.f, 0.f, 0.f, 0.f}; pb[g2] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        if (f < nfr) {                                          // (uniform)
+            f32x4 acc[FN];
+            product_frag<K, J>(xn, wn, P, lane, f, acc);
+            f32x4 gam[G2];
+#pragma unroll
+            for (int g2 = 0; g2 < G2; ++g2) gam[g2] = *reinterpret_cast<const f32x4*>(gamma + 64 * g2 + 4 * jj);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = 16 * f + 4 * kk + e;
+                const bool ok = row < P;
+                const size_t ro = ((size_t)n * P + (ok ? row : 0)) * J + 4 * jj;
+                const float mu = stats[((size_t)n * P + (ok ? row : 0)) * 2], rs = stats[((size_t)n * P + (ok ? row : 0)) * 2 + 1];
+                f32x4 gv[G2], xh[G2];
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int g2 = 0; g2 < G2; ++g2) {
+                    const f32x4 dyv = *reinterpret_cast<const f32x4*>(dy + ro + 64 * g2);
+                    const f32x4 yv = *reinterpret_cast<const f32x4*>(y + ro + 64 * g2);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const float gg = (ok && yv[t] > 0.f) ? dyv[t] : 0.f;
+                        const float h = (acc[4 * g2 + t][e] - mu) * rs;
+                        xh[g2][t] = h;
+                        pw[g2][t] += gg * h;
+                        pb[g2][t] += gg;
+                        const float v = gg * gam[g2][t];
+                        gv[g2][t] = v;
+                        s1 += v; s2 += v * h;
+                    }
+                }
+                s1 = group16_sum(s1) * (1.0f / (float)J);
+                s2 = group16_sum(s2) * (1.0f / (float)J);
+#pragma unroll
+                for (int g2 = 0; g2 < G2; ++g2) {
+                    f32x4 d;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) d[t] = ok ? rs * (gv[g2][t] - s1 - xh[g2][t] * s2) : 0.f;
+                    *reinterpret_cast<f32x4*>(Fs + row * PITCH + 64 * g2 + 4 * jj) = d;           // dF, zero rows past P
+                }
+            }
+        } else {                                                // a fragment without rows: its dF rows are zeros
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int g2 = 0; g2 < G2; ++g2)
+                    *reinterpret_cast<f32x4*>(Fs + (16 * f + 4 * kk + e) * PITCH + 64 * g2 + 4 * jj) = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        // the fragment's LayerNorm affine partials: the lane's column sums over its 4 rows, then over the four row groups kk
+#pragma unroll
+        for (int g2 = 0; g2 < G2; ++g2)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                float a = pw[g2][t], b = pb[g2][t];
+                a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+                b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+                pw[g2][t] = a; pb[g2][t] = b;
+            }
+        if (kk == 0) {
+#pragma unroll
+            for (int g2 = 0; g2 < G2; ++g2) {
+                *reinterpret_cast<f32x4*>(lp + (f * 2 + 0) * J + 64 * g2 + 4 * jj) = pw[g2];
+                *reinterpret_cast<f32x4*>(lp + (f * 2 + 1) * J + 64 * g2 + 4 * jj) = pb[g2];
+            }
+        }
+    }
+    __syncthreads();
+    if (wv == 3) {                                              // fold the three fragments' partials in a fixed order
+        for (int i = lane; i < 2 * J; i += 64)
+            lnpart[(size_t)n * 2 * J + i] = (lp[i] + lp[2 * J + i]) + lp[4 * J + i];
+    } else if (dx && wv < nfr) {
+        // ---- dX[p][k] = sum_j dF[p][j] * w[k][j], rows of fragment wv ----
+        const int f = wv;
+        float a[JS];
+        {
+            const int row = 16 * f + jj;
+            const bool ok = row < P;
+            const f32x4* src = reinterpret_cast<const f32x4*>(Fs + (ok ? row : 0) * PITCH + JS * kk);
+#pragma unroll
+            for (int t = 0; t < JS / 4; ++t) {
+                const f32x4 v = src[t];
+                a[4 * t] = ok ? v.x : 0.f; a[4 * t + 1] = ok ? v.y : 0.f; a[4 * t + 2] = ok ? v.z : 0.f; a[4 * t + 3] = ok ? v.w : 0.f;
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < FK; ++g) {
+            float b[JS];
+            const f32x4* src = reinterpret_cast<const f32x4*>(wn + (size_t)(16 * g + jj) * J + JS * kk);
+#pragma unroll
+            for (int t = 0; t < JS / 4; ++t) { const f32x4 v = src[t]; b[4 * t] = v.x; b[4 * t + 1] = v.y; b[4 * t + 2] = v.z; b[4 * t + 3] = v.w; }
+            f32x4 ax = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < JS; ++s) ax = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], ax, 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = 16 * f + 4 * kk + e;
+                if (row < P) dx[((size_t)n * P + row) * K + 16 * g + jj] = ax[e];
+            }
+        }
+    }
+    // ---- dW[k][j] = sum_p x[p][k] * dF[p][j]: row blocks fk = FKW wv .. of this wave, all points ----
+    {
+        const int RS = (P + 3) >> 2;                             // reduction steps: p = RS * kk + s
+        f32x4 aw[FKW][FN];
+#pragma unroll
+        for (int i = 0; i < FKW; ++i)
+#pragma unroll
+            for (int g = 0; g < FN; ++g) aw[i][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < RS; ++s) {
+            const int p = RS * kk + s;
+            const bool ok = p < P;
+            float av[FKW];
+#pragma unroll
+            for (int i = 0; i < FKW; ++i) { const float v = xn[(size_t)(ok ? p : 0) * K + 16 * (FKW * wv + i) + jj]; av[i] = ok ? v : 0.f; }
+            f32x4 bv[G2];
+#pragma unroll
+            for (int g2 = 0; g2 < G2; ++g2) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(Fs + (ok ? p : 0) * PITCH + 64 * g2 + 4 * jj);
+                bv[g2] = ok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int g = 0; g < FN; ++g)
+#pragma unroll
+                for (int i = 0; i < FKW; ++i)
+                    aw[i][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[g >> 2][g & 3], aw[i][g], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < FKW; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float* dst = dw + ((size_t)n * K + 16 * (FKW * wv + i) + 4 * kk + e) * J + 4 * jj;
+#pragma unroll
+                for (int g2 = 0; g2 < G2; ++g2)
+                    *reinterpret_cast<f32x4*>(dst + 64 * g2) = (f32x4){aw[i][4 * g2][e], aw[i][4 * g2 + 1][e], aw[i][4 * g2 + 2][e], aw[i][4 * g2 + 3][e]};
+            }
+    }
+}
+
 }  // namespace
 
-int g_dyn_rows = 1;             // forward: one wavefront per (anchor, row fragment); phnet_tune_dyn_mfma(2 | ...) switches it off
+int g_dyn_rows = 1;             // forward: one wavefront per (anchor, row fragment); backward: four wavefronts per anchor; phnet_tune_dyn_mfma(2 | ...) switches both off
 
 PHNET_API int phnet_dyn_mfma_applies(int32_t P, int32_t K, int32_t J)
 {
@@ -390,6 +555,12 @@ PHNET_API int phnet_dyn_mfma_bwd(const float* dy, const float* x, const float* w
 {
     if (N < 1 || !phnet_dyn_mfma_applies(P, K, J) || !dy || !x || !w || !y || !stats || !gamma || !dw || !lnpart) return PHNET_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
+    if (g_dyn_rows) {                                           // one workgroup (four wavefronts) per anchor
+        const size_t lds4 = ((size_t)48 * (J + 4) + 6 * J) * sizeof(float);
+        if (K == 64) hipLaunchKernelGGL((dyn_mfma_bwd_split_kernel<64, 128>), dim3((unsigned)N), dim3(256), lds4, st, dy, x, w, y, stats, gamma, dx, dw, lnpart, N, P);
+        else hipLaunchKernelGGL((dyn_mfma_bwd_split_kernel<128, 64>), dim3((unsigned)N), dim3(256), lds4, st, dy, x, w, y, stats, gamma, dx, dw, lnpart, N, P);
+        return phnet_launch_status();
+    }
     const dim3 grid((unsigned)((N + 3) / 4));
     const size_t lds = (size_t)4 * 36 * (J + 4) * sizeof(float);
     static bool attr_a = false, attr_b = false;

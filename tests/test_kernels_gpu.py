@@ -708,6 +708,15 @@ def test_dynamic_head_bmm_layernorm_relu(ops, N, P, K, J):
         assert torch.equal(y_a, yd) and torch.equal(st_a, stats)
     dx, dw, dg, db = ops.dyn_bmm_ln_relu_bwd(dev(g.float()), xd, wd, yd, stats, gd, 1e-5)
     close(dx, x.grad, 5e-5); close(dw, w.grad, 5e-5); close(dg, ga.grad, 5e-5); close(db, be.grad, 5e-5)
+    if lib().phnet_dyn_mfma_applies(P, K, J):
+        # matrix-pipe backward: four wavefronts per anchor by default, one with the switch - the same arithmetic up to the compiler's
+        # contraction of the LayerNorm-backward expressions and the order in which the row fragments' affine sums are folded
+        assert lib().phnet_tune_dyn_mfma(3) == 0
+        try:
+            dx_a, dw_a, dg_a, db_a = ops.dyn_bmm_ln_relu_bwd(dev(g.float()), xd, wd, yd, stats, gd, 1e-5)
+        finally:
+            assert lib().phnet_tune_dyn_mfma(1) == 0
+        close(dx_a, dx, 2e-6); close(dw_a, dw, 2e-6); close(dg_a, dg, 2e-6); close(db_a, db, 2e-6)
     # accumulate mode adds to the destinations; dx may be skipped
     acc_g, acc_b = torch.ones_like(gd), torch.ones_like(gd)
     dx2, dw2, _, _ = ops.dyn_bmm_ln_relu_bwd(dev(g.float()), xd, wd, yd, stats, gd, 1e-5, need_dx=False,
